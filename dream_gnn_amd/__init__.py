@@ -1,0 +1,20 @@
+"""dream_gnn_amd — MI355X-native message passing for DREAM-GNN's GCMC/FGCN hot path.
+
+The package holds only what the path needs:
+
+* ``csrc/`` + ``libdgmi.so`` — hand-written gfx950 HIP kernels behind the C ABI of
+  ``include/dgmi.h`` (CSR SpMM with fused diagonal scalings, device COO->CSR);
+* ``ops``      — torch-facing wrappers (device pointers + current stream -> C ABI) and the
+  autograd formula;
+* ``graph``    — the light graph containers the modules consume in place of DGL graphs;
+* ``layers``   — drop-in ``GCMCGraphConv`` / ``GCMCLayer`` / ``GraphConvolution`` / ``GCN`` /
+  ``FGCN`` with the reference's signatures and ``state_dict`` keys (reference layers.py);
+* ``shard``    — nnz-balanced edge partition + RCCL exchange for the multi-GPU configs.
+
+There is no CPU fallback: every op raises if ``libdgmi.so`` is missing or a tensor is
+not on a HIP device.
+"""
+from . import _lib  # noqa: F401  (fails loudly if the extension is not built)
+from .ops import csr_from_coo, spmm_csr, CSRGraph  # noqa: F401
+
+__all__ = ["csr_from_coo", "spmm_csr", "CSRGraph"]

@@ -1,0 +1,57 @@
+"""ctypes binding of ``libdgmi.so`` (the C ABI declared in ``include/dgmi.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``csrc/Makefile``.  A missing
+library is an error at import time: the product path has no fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  -- must come first: libdgmi.so binds to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdgmi.so")
+
+ABI_VERSION = 1
+
+# name -> (restype, argtypes); mirrors include/dgmi.h one to one.
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+SIGNATURES = {
+    "dgmi_abi_version": (ctypes.c_int, []),
+    "dgmi_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "dgmi_device_ok": (ctypes.c_int, []),
+    "dgmi_csr_from_coo_i32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp,
+                                             ctypes.POINTER(ctypes.c_size_t), _vp]),
+    "dgmi_spmm_csr_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "dgmi_gather_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
+}
+
+
+class DgmiError(RuntimeError):
+    """A non-zero dgmi_status came back from the C ABI."""
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "dream_gnn_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C dream_gnn_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export what dgmi.h declares
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.dgmi_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError("libdgmi.so ABI version %d != expected %d; rebuild" % (got, ABI_VERSION))
+    return lib
+
+
+lib = _load()
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise DgmiError("%s failed: %s (status %d)" % (what, lib.dgmi_status_string(status).decode(), status))

@@ -1,0 +1,92 @@
+// dgmi_api.hip — the extern "C" boundary declared in include/dgmi.h.
+// Host-side validation only; the kernels live in dgmi_spmm.hip / dgmi_csr.hip.
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <string.h>
+
+#include "dgmi.h"
+#include "dgmi_kernels.h"
+
+namespace {
+
+inline hipStream_t as_stream(dgmi_stream_t s) { return static_cast<hipStream_t>(s); }
+
+inline int from_hip(hipError_t e) { return e == hipSuccess ? DGMI_OK : DGMI_ERR_LAUNCH; }
+
+}  // namespace
+
+extern "C" {
+
+DGMI_API int dgmi_abi_version(void) { return DGMI_ABI_VERSION; }
+
+DGMI_API const char* dgmi_status_string(int status) {
+  switch (status) {
+    case DGMI_OK: return "ok";
+    case DGMI_ERR_INVALID_ARG: return "invalid argument (null pointer, negative size or ld < F)";
+    case DGMI_ERR_TOO_LARGE: return "size does not fit the int32 id space";
+    case DGMI_ERR_WORKSPACE: return "workspace missing or too small";
+    case DGMI_ERR_LAUNCH: return "HIP launch failed";
+    case DGMI_ERR_NO_DEVICE: return "no gfx950 device visible";
+    default: return "unknown dgmi status";
+  }
+}
+
+DGMI_API int dgmi_device_ok(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+DGMI_API int dgmi_csr_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E, int64_t n_rows,
+                          int32_t* indptr, int32_t* indices, int32_t* eid, void* workspace,
+                          size_t* workspace_bytes, dgmi_stream_t stream) {
+  if (E < 0 || n_rows < 0 || workspace_bytes == nullptr) return DGMI_ERR_INVALID_ARG;
+  if (E > INT32_MAX || n_rows >= INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (workspace != nullptr) {
+    if (indptr == nullptr) return DGMI_ERR_INVALID_ARG;
+    if (E > 0 && (row == nullptr || col == nullptr || indices == nullptr || eid == nullptr))
+      return DGMI_ERR_INVALID_ARG;
+  }
+  size_t need = 0;
+  hipError_t err = dgmi::csr_from_coo_i32(row, col, E, n_rows, indptr, indices, eid, nullptr,
+                                          &need, as_stream(stream));
+  if (err != hipSuccess) return DGMI_ERR_LAUNCH;
+  if (workspace == nullptr) {
+    *workspace_bytes = need;
+    return DGMI_OK;
+  }
+  if (*workspace_bytes < need) return DGMI_ERR_WORKSPACE;
+  return from_hip(dgmi::csr_from_coo_i32(row, col, E, n_rows, indptr, indices, eid, workspace,
+                                         workspace_bytes, as_stream(stream)));
+}
+
+DGMI_API int dgmi_spmm_csr_f32(const int32_t* indptr, const int32_t* indices, const float* vals,
+                      const float* X, int64_t ldx, const float* src_scale,
+                      const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
+                      int64_t n_src, int64_t F, dgmi_stream_t stream) {
+  if (n_dst < 0 || n_src < 0 || F < 0) return DGMI_ERR_INVALID_ARG;
+  if (n_dst >= INT32_MAX || n_src >= INT32_MAX || F > INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (n_dst == 0 || F == 0) return DGMI_OK;
+  if (indptr == nullptr || Y == nullptr) return DGMI_ERR_INVALID_ARG;
+  if (ldx < F || ldy < F) return DGMI_ERR_INVALID_ARG;
+  // `indices` (and `vals`) are dereferenced only for rows with edges, so an edgeless
+  // graph may pass NULL for them; X may be NULL only when there is no source node.
+  if (X == nullptr && n_src > 0) return DGMI_ERR_INVALID_ARG;
+  if (static_cast<const void*>(X) == static_cast<const void*>(Y)) return DGMI_ERR_INVALID_ARG;
+  dgmi::SpmmArgs a{indptr, indices, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F};
+  return from_hip(dgmi::spmm_csr_f32(a, as_stream(stream)));
+}
+
+DGMI_API int dgmi_gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,
+                    dgmi_stream_t stream) {
+  if (n < 0) return DGMI_ERR_INVALID_ARG;
+  if (n == 0) return DGMI_OK;
+  if (in == nullptr || perm == nullptr || out == nullptr) return DGMI_ERR_INVALID_ARG;
+  return from_hip(dgmi::gather_f32(in, perm, n, out, as_stream(stream)));
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+// dgmi_csr.hip — device-side stable COO -> CSR for gfx950.
+//
+// Replaces the host/DGL graph build the reference pays every training step
+// (augmentation.py:65 builds a new dgl.heterograph from a randperm prefix;
+// DGL then sorts its edges by destination lazily) and the coalesce->CSR inside
+// th.spmm (layers.py:312) for the shuffled COO of augmentation.py:117-124.
+//
+// Pipeline (all on `stream`, no host sync, no atomics -> bit-exact & reproducible):
+//   1. iota + range check : tmp_eid[e] = e ; flag |= row[e] outside [0, n_rows)
+//   2. stable LSD radix sort of (row, e) pairs on the low ceil(log2 n_rows) bits
+//      — rocPRIM's device radix sort (a plain library primitive; stability is
+//      what makes eid the original order inside a row)
+//   3. row boundaries     : thread p in [0, E] compares sorted_row[p-1] / [p] and
+//      writes indptr[r] = p for every r in (prev, cur] — also fills empty rows
+//   4. gather             : indices[p] = col[eid[p]]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "dgmi_kernels.h"
+
+namespace dgmi {
+namespace {
+
+constexpr int kBlock = 256;
+
+__global__ __launch_bounds__(kBlock) void iota_check_kernel(const int32_t* __restrict__ row,
+                                                            int64_t E, int32_t n_rows,
+                                                            int32_t* __restrict__ tmp_eid,
+                                                            int32_t* __restrict__ flag) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  bool bad = false;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += stride) {
+    tmp_eid[e] = (int32_t)e;
+    const int32_t r = row[e];
+    bad |= (r < 0) | (r >= n_rows);
+  }
+  if (bad) *flag = 1;  // benign race: every writer stores the same value
+}
+
+__global__ __launch_bounds__(kBlock) void boundaries_gather_kernel(
+    const int32_t* __restrict__ sorted_row, const int32_t* __restrict__ eid,
+    const int32_t* __restrict__ col, int64_t E, int32_t n_rows,
+    int32_t* __restrict__ indptr, int32_t* __restrict__ indices) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p <= E; p += stride) {
+    // rows in (prev, cur] start at p.  Out-of-range ids (flagged in step 1) are
+    // clamped so no store leaves indptr[0..n_rows].
+    int32_t prev = p > 0 ? sorted_row[p - 1] : -1;
+    int32_t cur = p < E ? sorted_row[p] : n_rows;
+    prev = max(-1, min(prev, n_rows));
+    cur = max(-1, min(cur, n_rows));
+    for (int32_t r = prev + 1; r <= cur; ++r) indptr[r] = (int32_t)p;
+    if (p < E) indices[p] = col[eid[p]];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_f32_kernel(const float* __restrict__ in,
+                                                            const int32_t* __restrict__ perm,
+                                                            int64_t n, float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += stride)
+    out[p] = in[perm[p]];
+}
+
+inline unsigned grid_for(int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
+  return (unsigned)b;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline int bits_for(int64_t n_rows) {
+  int b = 1;
+  while (b < 32 && ((int64_t)1 << b) < n_rows) ++b;
+  return b;
+}
+
+}  // namespace
+
+hipError_t csr_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
+                            int64_t n_rows, int32_t* indptr, int32_t* indices,
+                            int32_t* eid, void* workspace, size_t* workspace_bytes,
+                            hipStream_t s) {
+  const int end_bit = bits_for(n_rows);
+  size_t sort_bytes = 0;
+  if (E > 0) {
+    hipError_t err = rocprim::radix_sort_pairs(
+        nullptr, sort_bytes, reinterpret_cast<const uint32_t*>(row),
+        static_cast<uint32_t*>(nullptr), static_cast<const int32_t*>(nullptr), eid,
+        (size_t)E, 0u, (unsigned)end_bit, s);
+    if (err != hipSuccess) return err;
+  }
+  const size_t off_flag = 0;
+  const size_t off_keys = 256;
+  const size_t off_iota = off_keys + align_up((size_t)E * 4, 256);
+  const size_t off_sort = off_iota + align_up((size_t)E * 4, 256);
+  const size_t total = off_sort + align_up(sort_bytes, 256);
+  if (workspace == nullptr) {
+    *workspace_bytes = total;
+    return hipSuccess;
+  }
+  if (*workspace_bytes < total) return hipErrorInvalidValue;
+
+  char* ws = static_cast<char*>(workspace);
+  int32_t* flag = reinterpret_cast<int32_t*>(ws + off_flag);
+  int32_t* keys_out = reinterpret_cast<int32_t*>(ws + off_keys);
+  int32_t* tmp_eid = reinterpret_cast<int32_t*>(ws + off_iota);
+  void* sort_tmp = ws + off_sort;
+
+  hipError_t err = hipMemsetAsync(flag, 0, 256, s);
+  if (err != hipSuccess) return err;
+  if (E > 0) {
+    hipLaunchKernelGGL(iota_check_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, row, E,
+                       (int32_t)n_rows, tmp_eid, flag);
+    err = rocprim::radix_sort_pairs(sort_tmp, sort_bytes, reinterpret_cast<const uint32_t*>(row),
+                                    reinterpret_cast<uint32_t*>(keys_out),
+                                    static_cast<const int32_t*>(tmp_eid), eid, (size_t)E, 0u,
+                                    (unsigned)end_bit, s);
+    if (err != hipSuccess) return err;
+  }
+  hipLaunchKernelGGL(boundaries_gather_kernel, dim3(grid_for(E + 1)), dim3(kBlock), 0, s,
+                     keys_out, eid, col, E, (int32_t)n_rows, indptr, indices);
+  return hipGetLastError();
+}
+
+hipError_t gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,
+                      hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_f32_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, in, perm, n, out);
+  return hipGetLastError();
+}
+
+}  // namespace dgmi

@@ -1,0 +1,129 @@
+/*
+ * dgmi.h — C ABI of libdgmi.so: the MI355X (gfx950) message-passing primitives
+ * that stand in for the two third-party kernel call sites of DREAM-GNN's
+ * layers.py.
+ *
+ * The reference has no FFI of its own: control leaves its Python at
+ *   (B-i)  layers.py:229-232  graph.update_all(fn.copy_u('h','m'), fn.sum('m','h'))
+ *                             -> DGL gspmm('copy_lhs','sum') over the in-edge CSR
+ *   (B-ii) layers.py:312      th.spmm(adj, support)
+ *                             -> ATen sparse-COO addmm
+ *   (f1)   data_loader.py:448 / augmentation.py:65  dgl.heterograph(...) + DGL's lazy
+ *                             COO->CSR build (stable by destination row)
+ *   (f2)   layers.py:364,378  graph.apply_edges(udf_u_mul_e)  (cat(h_src, h_dst) per edge)
+ * Every entry point below names the call site it replaces.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature; a stream is an opaque
+ *     `void*` holding a hipStream_t (NULL = the null stream).
+ *   - every pointer is a DEVICE pointer on the current HIP device unless the
+ *     parameter says "host".  All buffers are caller-owned; the library keeps
+ *     no state between calls and allocates nothing.
+ *   - calls are asynchronous on `stream`, re-entrant, and never synchronise.
+ *   - return value: DGMI_OK (0) or a negative dgmi_status; nothing throws,
+ *     nothing aborts.  Shapes are validated on the host before any launch;
+ *     index VALUES are range-checked only by dgmi_csr_from_coo_i32 (flag word
+ *     in the workspace, see below), not per SpMM launch.
+ *   - ids are int32 (the reference casts its graphs with .int(): train.py:199,
+ *     evaluation.py:33); features / scales / values are fp32, row-major.
+ */
+#ifndef DGMI_H_
+#define DGMI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGMI_ABI_VERSION 1
+
+/* exported-symbol marker (the library is built with -fvisibility=hidden) */
+#if defined(__GNUC__)
+#define DGMI_API __attribute__((visibility("default")))
+#else
+#define DGMI_API
+#endif
+
+typedef void* dgmi_stream_t; /* hipStream_t */
+
+typedef enum dgmi_status {
+  DGMI_OK = 0,
+  DGMI_ERR_INVALID_ARG = -1,    /* null pointer, negative size, ld < F ...        */
+  DGMI_ERR_TOO_LARGE = -2,      /* a count does not fit the int32 id space        */
+  DGMI_ERR_WORKSPACE = -3,      /* workspace missing or too small                 */
+  DGMI_ERR_LAUNCH = -4,         /* hipGetLastError() != hipSuccess after a launch */
+  DGMI_ERR_NO_DEVICE = -5       /* no gfx950 device visible                       */
+} dgmi_status;
+
+/* ABI version of the loaded library (== DGMI_ABI_VERSION it was built with). */
+DGMI_API int dgmi_abi_version(void);
+
+/* Static, NUL-terminated description of a dgmi_status. */
+DGMI_API const char* dgmi_status_string(int status);
+
+/* 1 if a HIP device is visible and its arch is gfx950, else 0. Host-only query. */
+DGMI_API int dgmi_device_ok(void);
+
+/* -------------------------------------------------------------------------
+ * (f1) COO -> CSR, stable by row.
+ * Replaces DGL's COO->CSR behind dgl.heterograph (data_loader.py:448,
+ * augmentation.py:65) and the coalesce->CSR inside th.spmm (layers.py:312).
+ *
+ *   indptr[r]            = #edges with row < r                (n_rows + 1 ints)
+ *   eid[p]               = original position of the p-th edge in row-major,
+ *                          ties (same row) kept in input order (stable)
+ *   indices[p]           = col[eid[p]]
+ * Duplicate (row, col) pairs are kept (multigraph semantics, as DGL and an
+ * uncoalesced torch COO both have).
+ *
+ * Workspace protocol: call with workspace == NULL to get the required size in
+ * *workspace_bytes (nothing is launched); then call again with a device
+ * buffer of at least that size.  The first int32 of the workspace is an error
+ * flag the launch sets to 1 if any row id is outside [0, n_rows): read it back
+ * after synchronising the stream if the ids are untrusted.
+ * E == 0 is valid (indptr is zero-filled).
+ */
+DGMI_API int dgmi_csr_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
+                          int64_t n_rows, int32_t* indptr, int32_t* indices,
+                          int32_t* eid, void* workspace, size_t* workspace_bytes,
+                          dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
+ * (B-i, B-ii) CSR SpMM with optional diagonal scalings:
+ *
+ *   Y[v, :] = dst_scale[v] * sum_{p in [indptr[v], indptr[v+1])}
+ *                 vals[p] * src_scale[indices[p]] * X[indices[p], :]
+ *
+ * vals == NULL      -> 1   : DGL copy_u -> sum          (layers.py:229-232)
+ * vals != NULL             : DGL u_mul_e -> sum == th.spmm(adj, support)
+ *                                                       (layers.py:312)
+ * src_scale != NULL        : fuses `feat * dropout(cj)` (layers.py:224-225)
+ * dst_scale != NULL        : fuses `rst * ci`           (layers.py:234)
+ * Rows with no edges produce zeros (DGL's sum reducer; torch.spmm likewise).
+ * X is (n_src, F) with leading dimension ldx >= F (elements); Y is (n_dst, F)
+ * with ldy >= F.  Y must not alias X.  `indices`/`vals` are read only for rows
+ * that have edges (an edgeless graph may pass NULL).  fp32 accumulate in a fixed order: the
+ * result is bitwise reproducible from run to run (no atomics).
+ * The backward of the op is the same call on the transposed CSR with the two
+ * scales swapped: dX = diag(src_scale) A^T diag(dst_scale) dY.
+ */
+DGMI_API int dgmi_spmm_csr_f32(const int32_t* indptr, const int32_t* indices,
+                      const float* vals, const float* X, int64_t ldx,
+                      const float* src_scale, const float* dst_scale, float* Y,
+                      int64_t ldy, int64_t n_dst, int64_t n_src, int64_t F,
+                      dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
+ * Gather of per-edge values through a permutation: out[p] = in[perm[p]].
+ * Used to carry th.spmm's COO values (utils.py:24) into CSR order with the
+ * eid array of dgmi_csr_from_coo_i32.
+ */
+DGMI_API int dgmi_gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,
+                    dgmi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGMI_H_ */

@@ -1,0 +1,165 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on seeded inputs.
+
+Tolerances (north_star): CSR indexing bit-exact; fp32 embeddings within 1e-5 relative
+(see _check_close for what "relative" is measured against).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def _rand_graph(rng, n_dst, n_src, E, skew=False, empty_rows=True):
+    if skew:
+        p = 1.0 / np.arange(1, n_dst + 1) ** 1.2
+        p /= p.sum()
+        dst = rng.choice(n_dst, size=E, p=p).astype(np.int32)
+    else:
+        dst = rng.integers(0, n_dst, size=E, dtype=np.int32)
+    if empty_rows and n_dst > 4:
+        dst[dst == 1] = 0
+        dst[dst == n_dst - 1] = n_dst - 2
+    src = rng.integers(0, n_src, size=E, dtype=np.int32)
+    return dst, src
+
+
+def _check_close(y_hip, y32, y64, yabs):
+    """(a) forward-error bound of any fp32 summation order, elementwise, against the f64 oracle;
+    (b) 1e-5 relative to the output's magnitude, against the f64 oracle;
+    (c) no further from the sequential-fp32 oracle than that oracle's own rounding + 1e-5 rel
+        (a 60k-edge row summed sequentially in fp32 is itself ~6e-5 off)."""
+    y_hip = y_hip.astype(np.float64)
+    err = np.abs(y_hip - y64)
+    bound = RTOL * yabs + 1e-30
+    assert np.all(err <= bound), "max err/bound = %g" % float((err / bound).max())
+    if y64.size == 0:
+        return
+    scale = max(float(np.abs(y64).max()), 1e-30)
+    assert float(err.max()) <= RTOL * scale, "rel err %g" % (float(err.max()) / scale)
+    assert float(np.abs(y_hip - y32).max()) <= float(np.abs(y32 - y64).max()) + RTOL * scale
+
+
+@pytest.mark.parametrize("F", [1, 3, 4, 8, 32, 64, 100, 127, 128, 256, 341, 344, 768])
+@pytest.mark.parametrize("mode", ["copy_u", "copy_u_scaled", "u_mul_e", "all"])
+def test_spmm_vs_oracle(oracle, dev, F, mode):
+    from dream_gnn_amd import ops
+
+    rng = np.random.default_rng(1000 + F)
+    n_dst, n_src, E = 257, 301, 9000
+    dst, src = _rand_graph(rng, n_dst, n_src, E)
+    X = rng.standard_normal((n_src, F)).astype(np.float32)
+    vals = rng.standard_normal(E).astype(np.float32) if mode in ("u_mul_e", "all") else None
+    ss = rng.uniform(0.1, 1.0, n_src).astype(np.float32) if mode in ("copy_u_scaled", "all") else None
+    ds = rng.uniform(0.1, 1.0, n_dst).astype(np.float32) if mode in ("copy_u_scaled", "all") else None
+
+    indptr, indices, eid = oracle.csr_from_coo(dst, src, n_dst)
+    v_csr = None if vals is None else vals[eid]
+    y32 = oracle.spmm_csr(indptr, indices, v_csr, X, ss, ds)
+    y64 = oracle.spmm_csr(indptr, indices, v_csr, X, ss, ds, acc="f64")
+    yabs = oracle.spmm_csr(indptr, indices, v_csr, X, ss, ds, acc="abs")
+
+    t = lambda a, dt=None: None if a is None else torch.from_numpy(a).to(dev)
+    g = ops.CSRGraph(t(dst), t(src), n_dst, n_src, vals=t(vals))
+    # CSR indexing: bit-exact
+    assert np.array_equal(g.indptr.cpu().numpy(), indptr)
+    assert np.array_equal(g.indices.cpu().numpy(), indices)
+    assert np.array_equal(g.eid.cpu().numpy(), eid)
+    y = ops.spmm_csr_raw(g.indptr, g.indices, g.vals, t(X), t(ss), t(ds))
+    torch.cuda.synchronize()
+    _check_close(y.cpu().numpy(), y32, y64, yabs)
+    # empty rows are exactly zero
+    deg = np.diff(indptr)
+    assert np.all(y.cpu().numpy()[deg == 0] == 0)
+
+
+@pytest.mark.parametrize("case", ["E0", "one_row", "one_edge", "long_row", "skew", "dups"])
+def test_spmm_edge_cases(oracle, dev, case):
+    from dream_gnn_amd import ops
+
+    rng = np.random.default_rng(7)
+    F = 128
+    if case == "E0":
+        n_dst, n_src = 5, 4
+        dst = np.zeros(0, np.int32); src = np.zeros(0, np.int32)
+    elif case == "one_row":
+        n_dst, n_src = 1, 50
+        dst = np.zeros(333, np.int32); src = rng.integers(0, n_src, 333, dtype=np.int32)
+    elif case == "one_edge":
+        n_dst, n_src = 3, 3
+        dst = np.array([2], np.int32); src = np.array([1], np.int32)
+    elif case == "long_row":
+        n_dst, n_src = 40, 2000
+        dst = np.concatenate([np.full(20000, 17, np.int32), rng.integers(0, n_dst, 500, dtype=np.int32)])
+        src = rng.integers(0, n_src, dst.shape[0], dtype=np.int32)
+    elif case == "skew":
+        n_dst, n_src = 3000, 1000
+        dst, src = _rand_graph(rng, n_dst, n_src, 200000, skew=True)
+    else:  # duplicates: multigraph semantics, every copy counts
+        n_dst, n_src = 10, 10
+        dst = np.array([3, 3, 3, 3, 5, 5], np.int32); src = np.array([2, 2, 2, 7, 1, 1], np.int32)
+    X = rng.standard_normal((n_src, F)).astype(np.float32)
+    indptr, indices, eid = oracle.csr_from_coo(dst, src, n_dst)
+    y32 = oracle.spmm_csr(indptr, indices, None, X)
+    y64 = oracle.spmm_csr(indptr, indices, None, X, acc="f64")
+    yabs = oracle.spmm_csr(indptr, indices, None, X, acc="abs")
+    g = ops.CSRGraph(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n_dst, n_src)
+    assert np.array_equal(g.indptr.cpu().numpy(), indptr)
+    assert np.array_equal(g.indices.cpu().numpy(), indices)
+    assert np.array_equal(g.eid.cpu().numpy(), eid)
+    y = ops.spmm_csr_raw(g.indptr, g.indices, None, torch.from_numpy(X).to(dev))
+    torch.cuda.synchronize()
+    _check_close(y.cpu().numpy(), y32, y64, yabs)
+
+
+def test_strided_input_and_determinism(oracle, dev):
+    from dream_gnn_amd import ops
+
+    rng = np.random.default_rng(3)
+    n_dst, n_src, E, F = 500, 400, 30000, 128
+    dst, src = _rand_graph(rng, n_dst, n_src, E)
+    Xbig = rng.standard_normal((n_src, 2 * F)).astype(np.float32)
+    g = ops.CSRGraph(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), n_dst, n_src)
+    xb = torch.from_numpy(Xbig).to(dev)
+    y1 = ops.spmm_csr_raw(g.indptr, g.indices, None, xb[:, F:])  # row-strided view, ldx = 2F
+    y2 = ops.spmm_csr_raw(g.indptr, g.indices, None, xb[:, F:].contiguous())
+    y3 = ops.spmm_csr_raw(g.indptr, g.indices, None, xb[:, F:])
+    assert torch.equal(y1, y2) and torch.equal(y1, y3)  # bitwise reproducible
+    indptr, indices, _ = oracle.csr_from_coo(dst, src, n_dst)
+    y32 = oracle.spmm_csr(indptr, indices, None, np.ascontiguousarray(Xbig[:, F:]))
+    assert np.abs(y1.cpu().numpy() - y32).max() <= RTOL * np.abs(y32).max()
+
+
+def test_autograd_is_transpose_spmm(oracle, dev):
+    from dream_gnn_amd import ops
+
+    rng = np.random.default_rng(11)
+    n_dst, n_src, E, F = 300, 200, 5000, 128
+    dst, src = _rand_graph(rng, n_dst, n_src, E)
+    vals = rng.standard_normal(E).astype(np.float32)
+    ss = rng.uniform(0.1, 1, n_src).astype(np.float32)
+    ds = rng.uniform(0.1, 1, n_dst).astype(np.float32)
+    X = rng.standard_normal((n_src, F)).astype(np.float32)
+    dY = rng.standard_normal((n_dst, F)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    g = ops.CSRGraph(t(dst), t(src), n_dst, n_src, vals=t(vals))
+    x = t(X).requires_grad_(True)
+    y = ops.spmm_csr(g, x, t(ss), t(ds))
+    y.backward(t(dY))
+    # oracle: dX = diag(ss) A^T diag(ds) dY on the reversed edges
+    indptr_t, indices_t, eid_t = oracle.csr_from_coo(src, dst, n_src)
+    ref = oracle.spmm_csr(indptr_t, indices_t, vals[eid_t], dY, ds, ss, acc="f64")
+    refabs = oracle.spmm_csr(indptr_t, indices_t, vals[eid_t], dY, ds, ss, acc="abs")
+    err = np.abs(x.grad.cpu().numpy().astype(np.float64) - ref)
+    assert np.all(err <= RTOL * refabs + 1e-30)
+
+
+def test_out_of_range_row_is_reported(dev):
+    from dream_gnn_amd import ops
+
+    row = torch.tensor([0, 5, 1], dtype=torch.int32, device=dev)
+    col = torch.tensor([0, 0, 0], dtype=torch.int32, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.csr_from_coo(row, col, 3, check_range=True)
