@@ -1,0 +1,312 @@
+"""Light graph containers consumed by the drop-in modules in place of DGL graphs.
+
+The reference hands its layers a DGL heterograph built by
+``DrugDataLoader._generate_enc_graph`` (reference data_loader.py:400-490): canonical edge
+types ``('drug', r, 'disease')`` and ``('disease', 'rev-'+r, 'drug')`` for each rating ``r``,
+with per-node-type data ``ci`` / ``cj`` (N,1) fp32.  ``HeteroGraph`` keeps that shape of API —
+only the members the reference's layers / augmentation actually touch — on top of device
+COO tensors and lazily built device CSRs (``ops.CSRGraph``).  Nothing here depends on DGL.
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import ops
+
+CanonicalEType = Tuple[str, str, str]
+
+
+class _NodeView:
+    def __init__(self, data: dict):
+        self.data = data
+
+
+class _NodeSpace:
+    """``graph.nodes[ntype].data`` (layers.py:362-363, data_loader.py:487-488)."""
+
+    def __init__(self, store: Dict[str, dict]):
+        self._store = store
+
+    def __getitem__(self, ntype: str) -> _NodeView:
+        return _NodeView(self._store[ntype])
+
+
+class RelationGraph:
+    """One canonical edge type of a :class:`HeteroGraph`: edges ``src_type -> dst_type``.
+
+    This is what ``GCMCGraphConv.forward`` receives (layers.py:169): it exposes ``srcdata`` /
+    ``dstdata`` (views of the parent's node data), ``number_of_src_nodes`` and ``local_scope``
+    (layers.py:174-190), plus ``csr`` — the destination-major CSR the HIP kernel reads.
+    """
+
+    def __init__(self, canonical: CanonicalEType, src: torch.Tensor, dst: torch.Tensor,
+                 n_src: int, n_dst: int, srcdata: dict, dstdata: dict):
+        self.canonical = canonical
+        self.src, self.dst = src, dst
+        self.n_src, self.n_dst = int(n_src), int(n_dst)
+        self.srcdata, self.dstdata = srcdata, dstdata
+        self._csr: Optional[ops.CSRGraph] = None
+
+    # -- the DGL surface the reference's layer code uses ---------------------------------
+    def number_of_src_nodes(self) -> int:
+        return self.n_src
+
+    def number_of_dst_nodes(self) -> int:
+        return self.n_dst
+
+    def number_of_edges(self) -> int:
+        return int(self.src.shape[0])
+
+    def edges(self):
+        return self.src, self.dst
+
+    @property
+    def device(self):
+        return self.src.device
+
+    def in_degrees(self) -> torch.Tensor:
+        return torch.bincount(self.dst.long(), minlength=self.n_dst)
+
+    def out_degrees(self) -> torch.Tensor:
+        return torch.bincount(self.src.long(), minlength=self.n_src)
+
+    @contextlib.contextmanager
+    def local_scope(self):
+        """Node-data keys written inside the scope vanish on exit (layers.py:174)."""
+        saved_src, saved_dst = dict(self.srcdata), dict(self.dstdata)
+        try:
+            yield self
+        finally:
+            for live, saved in ((self.srcdata, saved_src), (self.dstdata, saved_dst)):
+                live.clear()
+                live.update(saved)
+
+    # -- kernel-side layout -----------------------------------------------------------------
+    @property
+    def csr(self) -> ops.CSRGraph:
+        if self._csr is None:
+            self._csr = ops.CSRGraph(self.dst, self.src, self.n_dst, self.n_src)
+        return self._csr
+
+
+class HeteroGraph:
+    """Bipartite heterograph: ``{(src_type, etype, dst_type): (src_ids, dst_ids)}``.
+
+    Constructor arguments follow ``dgl.heterograph(data_dict, num_nodes_dict=...)`` as the
+    reference calls it (data_loader.py:448, augmentation.py:65).  Edge order inside an edge
+    type is the caller's order; the CSR build is stable, so that order is the in-row
+    summation order, as with DGL.
+    """
+
+    def __init__(self, data_dict: Dict[CanonicalEType, Tuple[torch.Tensor, torch.Tensor]],
+                 num_nodes_dict: Dict[str, int], device=None):
+        self._num_nodes = {k: int(v) for k, v in num_nodes_dict.items()}
+        self._ndata: Dict[str, dict] = {nt: {} for nt in self._num_nodes}
+        self._rels: Dict[CanonicalEType, RelationGraph] = {}
+        self.nodes = _NodeSpace(self._ndata)
+        for can, (src, dst) in data_dict.items():
+            st, _, dt = can
+            src = torch.as_tensor(src)
+            dst = torch.as_tensor(dst)
+            if device is not None:
+                src, dst = src.to(device), dst.to(device)
+            if src.shape != dst.shape or src.dim() != 1:
+                raise ValueError("edge lists of %s must be two 1-D tensors of equal length" % (can,))
+            self._rels[can] = RelationGraph(can, src, dst, self._num_nodes[st], self._num_nodes[dt],
+                                            self._ndata[st], self._ndata[dt])
+
+    # -- DGL-shaped accessors -----------------------------------------------------------------
+    @property
+    def ntypes(self):
+        return list(self._num_nodes)
+
+    @property
+    def canonical_etypes(self):
+        return list(self._rels)
+
+    @property
+    def etypes(self):
+        return [c[1] for c in self._rels]
+
+    @property
+    def device(self):
+        for r in self._rels.values():
+            return r.device
+        return torch.device("cpu")
+
+    def _canonical(self, key) -> CanonicalEType:
+        if isinstance(key, tuple):
+            return key
+        hits = [c for c in self._rels if c[1] == key]
+        if len(hits) != 1:
+            raise KeyError("edge type %r matches %d relations" % (key, len(hits)))
+        return hits[0]
+
+    def __getitem__(self, key) -> RelationGraph:
+        return self._rels[self._canonical(key)]
+
+    def number_of_nodes(self, ntype: str) -> int:
+        return self._num_nodes[ntype]
+
+    def number_of_edges(self, etype=None) -> int:
+        if etype is None:
+            return sum(r.number_of_edges() for r in self._rels.values())
+        return self[etype].number_of_edges()
+
+    def edges(self, etype=None):
+        return self[etype].edges()
+
+    def int(self) -> "HeteroGraph":
+        """``graph.int()`` (train.py:199, evaluation.py:33): ids to int32, in place of a copy."""
+        for r in self._rels.values():
+            if r.src.dtype != torch.int32:
+                r.src, r.dst = r.src.to(torch.int32), r.dst.to(torch.int32)
+                r._csr = None
+        return self
+
+    def to(self, device) -> "HeteroGraph":
+        device = torch.device(device) if not isinstance(device, torch.device) else device
+        for r in self._rels.values():
+            if r.src.device != device:
+                r.src, r.dst = r.src.to(device), r.dst.to(device)
+                r._csr = None
+        for store in self._ndata.values():
+            for k, v in list(store.items()):
+                store[k] = v.to(device)
+        return self
+
+    # -- decoder-side surface (layers.py:360-365) ------------------------------------------------
+    @contextlib.contextmanager
+    def local_scope(self):
+        saved = {nt: dict(d) for nt, d in self._ndata.items()}
+        saved_e = getattr(self, "edata", None)
+        self.edata = {}
+        try:
+            yield self
+        finally:
+            for nt, d in self._ndata.items():
+                d.clear()
+                d.update(saved[nt])
+            if saved_e is None:
+                del self.edata
+            else:
+                self.edata = saved_e
+
+    def apply_edges(self, udf, etype=None):
+        """``graph.apply_edges(udf)`` for a single-relation graph (the decoder graph,
+        data_loader.py:508): the UDF sees per-edge source / destination node data."""
+        rel = self[etype] if etype is not None else self._single()
+
+        class _Edges:
+            pass
+
+        e = _Edges()
+        e.src = {k: v.index_select(0, rel.src.long()) for k, v in rel.srcdata.items()}
+        e.dst = {k: v.index_select(0, rel.dst.long()) for k, v in rel.dstdata.items()}
+        if not hasattr(self, "edata"):
+            self.edata = {}
+        self.edata.update(udf(e))
+
+    def _single(self) -> RelationGraph:
+        if len(self._rels) != 1:
+            raise ValueError("graph has %d edge types; name one" % len(self._rels))
+        return next(iter(self._rels.values()))
+
+
+# ---------------------------------------------------------------------------------------------
+# builders for the data formats either side of the path
+# ---------------------------------------------------------------------------------------------
+def _etype_name(rating) -> str:
+    if rating == 0:
+        return "0"
+    if rating == 1:
+        return "1"
+    return str(rating).replace(".", "_")
+
+
+def build_enc_graph(drug_ids: torch.Tensor, dis_ids: torch.Tensor, values: torch.Tensor,
+                    n_drug: int, n_dis: int, symm: bool = True, add_support: bool = True,
+                    device=None) -> HeteroGraph:
+    """Encoder graph in the reference's format — data_loader.py:400-490.
+
+    One relation pair per distinct rating value (``'0'``/``'rev-0'``, ``'1'``/``'rev-1'``),
+    ``ci = 1/sqrt(total in-degree)`` and, with ``symm``, ``cj = 1/sqrt(total out-degree)``;
+    isolated nodes get 0 (data_loader.py:454-457).
+    """
+    drug_ids = torch.as_tensor(drug_ids)
+    dis_ids = torch.as_tensor(dis_ids)
+    values = torch.as_tensor(values)
+    if device is not None:
+        drug_ids, dis_ids, values = drug_ids.to(device), dis_ids.to(device), values.to(device)
+    data = {}
+    for rating in torch.unique(values).tolist():
+        sel = (values == rating).nonzero(as_tuple=True)[0]
+        name = _etype_name(int(rating) if float(rating).is_integer() else rating)
+        d, s = drug_ids[sel], dis_ids[sel]
+        data[("drug", name, "disease")] = (d, s)
+        data[("disease", "rev-" + name, "drug")] = (s, d)
+    g = HeteroGraph(data, {"drug": n_drug, "disease": n_dis})
+    if add_support:
+        def calc_norm(deg):
+            deg = deg.to(torch.float32)
+            deg = torch.where(deg == 0, torch.full_like(deg, float("inf")), deg)
+            return (1.0 / torch.sqrt(deg)).unsqueeze(1)
+
+        drug_deg = torch.bincount(drug_ids.long(), minlength=n_drug)
+        dis_deg = torch.bincount(dis_ids.long(), minlength=n_dis)
+        drug_ci, dis_ci = calc_norm(drug_deg), calc_norm(dis_deg)
+        if symm:
+            drug_cj, dis_cj = calc_norm(drug_deg), calc_norm(dis_deg)
+        else:
+            drug_cj = torch.ones(n_drug, device=drug_ids.device)
+            dis_cj = torch.ones(n_dis, device=drug_ids.device)
+        g.nodes["drug"].data.update({"ci": drug_ci, "cj": drug_cj})
+        g.nodes["disease"].data.update({"ci": dis_ci, "cj": dis_cj})
+    return g
+
+
+def build_dec_graph(drug_ids: torch.Tensor, dis_ids: torch.Tensor, n_drug: int, n_dis: int,
+                    device=None) -> HeteroGraph:
+    """Decoder graph — data_loader.py:492-509: one relation ``('drug','rate','disease')``."""
+    return HeteroGraph({("drug", "rate", "disease"): (torch.as_tensor(drug_ids), torch.as_tensor(dis_ids))},
+                       {"drug": n_drug, "disease": n_dis}, device=device)
+
+
+def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
+                        generator: Optional[torch.Generator] = None) -> HeteroGraph:
+    """Edge dropout on the encoder graph — augmentation.py:13-89.
+
+    Per edge type independently, keep the first ``max(1, int(E*(1-p)))`` entries of a random
+    permutation (so ``rev-r`` stops being the transpose of ``r``); node data is *copied, not
+    recomputed* (augmentation.py:68-70), so ``ci``/``cj`` go stale exactly as in the reference.
+    The new graph's CSRs are rebuilt on the device on first use.
+    """
+    data = {}
+    for can in graph.canonical_etypes:
+        rel = graph[can]
+        E = rel.number_of_edges()
+        if E == 0:
+            data[can] = (rel.src, rel.dst)
+            continue
+        keep = max(1, int(E * (1 - dropout_rate)))
+        perm = torch.randperm(E, device=rel.device, generator=generator)[:keep]
+        data[can] = (rel.src[perm], rel.dst[perm])
+    out = HeteroGraph(data, {nt: graph.number_of_nodes(nt) for nt in graph.ntypes})
+    for nt in graph.ntypes:
+        for k, v in graph.nodes[nt].data.items():
+            out.nodes[nt].data[k] = v.clone()
+    return out
+
+
+def random_edge_dropout_sparse(adj: torch.Tensor, dropout_rate: float = 0.1,
+                               generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """Edge dropout on a sparse COO adjacency — augmentation.py:92-124 (uncoalesced result,
+    random entry order)."""
+    idx, val = adj._indices(), adj._values()
+    E = val.shape[0]
+    keep = max(1, int(E * (1 - dropout_rate)))
+    perm = torch.randperm(E, device=adj.device, generator=generator)[:keep]
+    return torch.sparse_coo_tensor(idx[:, perm], val[perm], adj.shape, device=adj.device)

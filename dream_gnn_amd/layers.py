@@ -1,0 +1,353 @@
+"""Drop-in message-passing modules for DREAM-GNN on MI355X.
+
+Same class names, constructor arguments, ``forward`` signatures and ``state_dict`` keys as the
+reference's ``layers.py`` (``GCMCLayer`` :18-143, ``GCMCGraphConv`` :146-236, ``GCN`` :238-249,
+``FGCN`` :251-285, ``GraphConvolution`` :287-321, ``dot_or_identity`` :382-392), so the
+reference's ``model.py`` / ``train.py`` keep working when these are imported in their place.
+What changes is underneath: the two third-party kernel call sites
+
+  * ``graph.update_all(fn.copy_u('h','m'), fn.sum('m','h'))``   (layers.py:229-232)
+  * ``th.spmm(adj, support)``                                     (layers.py:312)
+
+become one ``dgmi_spmm_csr_f32`` launch each (``ops.spmm_csr``), with the ``cj`` / ``ci``
+scalings of layers.py:224-225,234 fused into the same kernel.  No DGL import; graphs are
+``graph.HeteroGraph`` objects (or torch sparse COO tensors for the FGCN channel).
+"""
+from __future__ import annotations
+
+import math
+import warnings
+import weakref
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .graph import RelationGraph
+
+
+class DGMIError(RuntimeError):
+    """Raised where the reference raises ``dgl.DGLError`` (layers.py:216)."""
+
+
+def to_etype_name(rating) -> str:
+    """utils.py:83-84."""
+    return str(rating).replace(".", "_")
+
+
+def get_activation(act):
+    """utils.py:47-80 — activation by name, callable passthrough, identity for None."""
+    if act is None:
+        return lambda x: x
+    if not isinstance(act, str):
+        return act
+    table = {"leaky": lambda: nn.LeakyReLU(0.1), "relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid,
+             "softsign": nn.Softsign, "gelu": nn.GELU, "elu": nn.ELU, "selu": nn.SELU}
+    if act not in table:
+        raise NotImplementedError
+    return table[act]()
+
+
+def dot_or_identity(A, B, device=None):
+    """layers.py:382-392, including the 3-column index-gather branch (:385-389)."""
+    if A is None:
+        return B
+    if A.shape[1] == 3:
+        cols = [B[A[:, j].long()] for j in range(3)]
+        out = torch.cat(cols, 1)
+        return out if device is None else out.to(device)
+    return torch.matmul(A, B)
+
+
+# -------------------------------------------------------------------------------------------
+# GCMC channel
+# -------------------------------------------------------------------------------------------
+class GCMCGraphConv(nn.Module):
+    """One relation slice: ``ci * (A_r @ (dropout(cj) * (feat @ W_r)))`` — layers.py:146-236.
+
+    The SpMM and both diagonal scalings run as one HIP kernel; ``nn.Dropout`` is still drawn
+    on ``cj`` with shape (N_src, 1), once per call, so the RNG stream matches the reference
+    (layers.py:224).
+    """
+
+    def __init__(self, in_feats, out_feats, weight=True, device=None, dropout_rate=0.1):
+        super().__init__()
+        self._in_feats = in_feats
+        self._out_feats = out_feats
+        self.device = device
+        self.dropout = nn.Dropout(dropout_rate)
+        if weight:
+            self.weight = nn.Parameter(torch.Tensor(in_feats, out_feats))
+        else:
+            self.register_parameter("weight", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if self.weight is not None:
+            nn.init.xavier_uniform_(self.weight)
+
+    @staticmethod
+    def _fit_rows(feat, cj, n_src):
+        # layers.py:190-212: a mismatched feature / cj row count is padded or truncated with a
+        # warning rather than rejected.  Never triggers on well-formed input.
+        if feat.size(0) != n_src:
+            warnings.warn("feat rows (%d) != source nodes (%d)" % (feat.size(0), n_src))
+            if feat.size(0) > n_src:
+                feat = feat[:n_src]
+            else:
+                feat = torch.cat([feat, feat[-1:].repeat(n_src - feat.size(0), 1)], 0)
+        if cj.size(0) != feat.size(0):
+            warnings.warn("cj rows (%d) != feat rows (%d)" % (cj.size(0), feat.size(0)))
+            if cj.size(0) > feat.size(0):
+                cj = cj[:feat.size(0)]
+            else:
+                cj = torch.cat([cj, torch.ones(feat.size(0) - cj.size(0), 1, device=cj.device)], 0)
+        return feat, cj
+
+    def forward(self, graph: RelationGraph, feat, weight=None, Two_Stage=False):
+        del Two_Stage  # accepted and ignored, as in the reference
+        with graph.local_scope():
+            if isinstance(feat, tuple):
+                feat = feat[0]  # destination-side features are unused (layers.py:175-176)
+            cj, ci = graph.srcdata["cj"], graph.dstdata["ci"]
+            if self.device is not None:
+                feat, cj, ci = feat.to(self.device), cj.to(self.device), ci.to(self.device)
+            feat, cj = self._fit_rows(feat, cj, graph.number_of_src_nodes())
+
+            if weight is not None and self.weight is not None:
+                raise DGMIError("External weight provided but module also has its own weight parameter, "
+                                "please set weight=False.")
+            if weight is None:
+                weight = self.weight
+            if weight is not None:
+                feat = dot_or_identity(feat, weight, self.device)
+
+            cj_drop = self.dropout(cj).view(-1, 1)
+            return ops.spmm_csr(graph.csr, feat, src_scale=cj_drop, dst_scale=ci)
+
+
+class HeteroGraphConv(nn.Module):
+    """The slice of ``dglnn.HeteroGraphConv`` the reference uses (layers.py:98,129): run
+    ``mods[etype]`` on every relation whose source type has an input, then combine the
+    per-destination-type results with ``aggregate``."""
+
+    def __init__(self, mods: Dict[str, nn.Module], aggregate="sum"):
+        super().__init__()
+        self.mods = nn.ModuleDict(mods)
+        if aggregate not in ("sum", "stack", "mean", "max", "min"):
+            raise DGMIError("unsupported aggregate %r" % (aggregate,))
+        self.aggregate = aggregate
+
+    def forward(self, g, inputs, mod_args=None, mod_kwargs=None):
+        mod_args = mod_args or {}
+        mod_kwargs = mod_kwargs or {}
+        per_dst = {nt: [] for nt in g.ntypes}
+        for can in g.canonical_etypes:
+            stype, etype, dtype = can
+            if stype not in inputs or inputs[stype] is None:
+                continue
+            out = self.mods[etype](g[can], (inputs[stype], inputs.get(dtype)),
+                                   *mod_args.get(etype, ()), **mod_kwargs.get(etype, {}))
+            per_dst[dtype].append(out)
+        result = {}
+        for nt, outs in per_dst.items():
+            if not outs:
+                continue
+            if self.aggregate == "stack":
+                result[nt] = torch.stack(outs, dim=1)
+                continue
+            stacked = torch.stack(outs, dim=0)
+            if self.aggregate == "sum":
+                result[nt] = stacked.sum(0)
+            elif self.aggregate == "mean":
+                result[nt] = stacked.mean(0)
+            elif self.aggregate == "max":
+                result[nt] = stacked.max(0)[0]
+            else:
+                result[nt] = stacked.min(0)[0]
+        return result
+
+
+class GCMCLayer(nn.Module):
+    """layers.py:18-143.  Parameters: ``att`` (R,B), ``basis`` (B,in,msg), ``ufc`` (and ``ifc``,
+    the same module when sharing), plus ``conv.mods.<etype>.weight`` in the unshared branch."""
+
+    def __init__(self, rating_vals, user_in_units, movie_in_units, msg_units, out_units,
+                 dropout_rate=0.1, agg="stack", agg_act=None, ini=True,
+                 share_user_item_param=False, basis_units=2, device=None):
+        super().__init__()
+        self.rating_vals = rating_vals
+        self.agg = agg
+        self.share_user_item_param = share_user_item_param
+        self.user_in_units = user_in_units
+        self.basis_units = basis_units
+        self.device = device
+
+        width = msg_units
+        if agg == "stack":  # layers.py:52-54
+            assert width % len(rating_vals) == 0
+            width //= len(rating_vals)
+        if ini:  # layers.py:55-56 — layer 0 of the model runs at msg_units // 3 (341 for 1024)
+            width //= 3
+        self.msg_units = width
+
+        self.ufc = nn.Linear(width, out_units)
+        self.ifc = self.ufc if share_user_item_param else nn.Linear(width, out_units)
+        self.dropout = nn.Dropout(dropout_rate)
+        self.att = nn.Parameter(torch.randn(len(rating_vals), basis_units))
+        self.basis = nn.Parameter(torch.randn(basis_units, user_in_units, width))
+
+        shared_w = share_user_item_param and user_in_units == movie_in_units  # layers.py:75
+        self.W_r = {} if shared_w else None  # truthiness is tested with `is not None` (:126)
+        sub = {}
+        for rating in rating_vals:
+            name = to_etype_name(rating)
+            sub[name] = GCMCGraphConv(user_in_units, width, weight=not shared_w, device=device,
+                                      dropout_rate=dropout_rate)
+            sub["rev-%s" % name] = GCMCGraphConv(user_in_units if shared_w else movie_in_units, width,
+                                                 weight=not shared_w, device=device,
+                                                 dropout_rate=dropout_rate)
+        self.conv = HeteroGraphConv(sub, aggregate=agg)
+        self.agg_act = get_activation(agg_act)
+        self.reset_parameters()
+
+    def partial_to(self, device):
+        assert device == self.device
+        if device is not None:
+            self.ufc.cuda(device)
+            if not self.share_user_item_param:
+                self.ifc.cuda(device)
+            self.dropout.cuda(device)
+
+    def reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, graph, drug_feat=None, dis_feat=None, Two_Stage=False):
+        # basis decomposition W_r = sum_b att[r,b] * basis[b]   (layers.py:120-121)
+        self.W = torch.matmul(self.att, self.basis.view(self.basis_units, -1)).view(
+            -1, self.user_in_units, self.msg_units)
+        mod_args = {}
+        for i, rating in enumerate(self.rating_vals):
+            name = to_etype_name(rating)
+            w = self.W[i] if self.W_r is not None else None
+            mod_args[name] = (w, Two_Stage)
+            mod_args["rev-%s" % name] = (w, Two_Stage)
+        out = self.conv(graph, {"drug": drug_feat, "disease": dis_feat}, mod_args=mod_args)
+        drug = self.dropout(self.agg_act(out["drug"]))
+        dis = self.dropout(self.agg_act(out["disease"]))
+        return self.ifc(drug), self.ufc(dis)
+
+
+# -------------------------------------------------------------------------------------------
+# FGCN channel
+# -------------------------------------------------------------------------------------------
+_ADJ_CACHE: Dict[int, tuple] = {}
+
+
+def adjacency_csr(adj) -> ops.CSRGraph:
+    """CSR (+ lazily its transpose) of a torch sparse COO adjacency, cached per tensor object.
+
+    ``adj`` is what ``utils.sparse_mx_to_torch_sparse_tensor`` (utils.py:20-27) or
+    ``random_edge_dropout_sparse`` (augmentation.py:92-124) produce: fp32 values, int64
+    indices, possibly uncoalesced and in random order.  Stored entries are kept one to one
+    (duplicates sum, as in ``th.spmm``); the device COO->CSR is stable.
+    """
+    if isinstance(adj, ops.CSRGraph):
+        return adj
+    key = id(adj)
+    hit = _ADJ_CACHE.get(key)
+    if hit is not None and hit[0]() is adj and hit[1] == adj._version:
+        return hit[2]
+    if not adj.is_sparse:
+        raise RuntimeError("GraphConvolution expects a sparse COO adjacency or a CSRGraph")
+    idx, val = adj._indices(), adj._values()
+    n_dst, n_src = adj.shape
+    if max(n_dst, n_src) >= 2 ** 31 - 1:
+        raise RuntimeError("adjacency too large for int32 ids")
+    g = ops.CSRGraph(idx[0].to(torch.int32), idx[1].to(torch.int32), n_dst, n_src, vals=val)
+    for k in [k for k, v in _ADJ_CACHE.items() if v[0]() is None]:
+        del _ADJ_CACHE[k]
+    _ADJ_CACHE[key] = (weakref.ref(adj), adj._version, g)
+    return g
+
+
+class GraphConvolution(nn.Module):
+    """``adj @ (input @ W) + b`` — layers.py:287-321, the sparse product on the HIP kernel."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.weight = nn.Parameter(torch.FloatTensor(in_features, out_features))
+        if bias:
+            self.bias = nn.Parameter(torch.FloatTensor(out_features))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = 1.0 / math.sqrt(self.weight.size(1))
+        self.weight.data.uniform_(-bound, bound)
+        if self.bias is not None:
+            self.bias.data.uniform_(-bound, bound)
+
+    def forward(self, input, adj):
+        if not isinstance(adj, ops.CSRGraph) and adj.device != input.device:
+            adj = adj.to(input.device)  # layers.py:307-309
+        support = torch.mm(input, self.weight)
+        output = ops.spmm_csr(adjacency_csr(adj), support)
+        return output if self.bias is None else output + self.bias
+
+    def __repr__(self):
+        return "%s (%d -> %d)" % (self.__class__.__name__, self.in_features, self.out_features)
+
+
+class GCN(nn.Module):
+    """layers.py:238-249."""
+
+    def __init__(self, features, nhid, nhid2, dropout):
+        super().__init__()
+        self.gc1 = GraphConvolution(features, nhid)
+        self.gc2 = GraphConvolution(nhid, nhid2)
+        self.dropout = dropout
+
+    def forward(self, x, adj):
+        x = F.dropout(F.relu(self.gc1(x, adj)), self.dropout, training=self.training)
+        return self.gc2(x, adj)
+
+
+class FGCN(nn.Module):
+    """layers.py:251-285: one GCN per node type, applied with shared weights to the similarity
+    graph and (optionally) the feature-kNN graph, fused by Linear+ReLU+dropout."""
+
+    def __init__(self, fdim_drug, fdim_disease, nhid1, nhid2, dropout):
+        super().__init__()
+        self.FGCN_drug = GCN(fdim_drug, nhid1, nhid2, dropout)
+        self.FGCN_disease = GCN(fdim_disease, nhid1, nhid2, dropout)
+        self.dropout = dropout
+        self.drug_fusion = nn.Linear(nhid2 * 2, nhid2)
+        self.disease_fusion = nn.Linear(nhid2 * 2, nhid2)
+
+    def forward(self, drug_graph, drug_sim_feat, dis_graph, disease_sim_feat,
+                drug_feature_graph=None, disease_feature_graph=None):
+        emb1_sim = self.FGCN_drug(drug_sim_feat, drug_graph)
+        emb2_sim = self.FGCN_disease(disease_sim_feat, dis_graph)
+        emb1_feat = emb2_feat = None
+        if drug_feature_graph is not None and disease_feature_graph is not None:
+            emb1_feat = self.FGCN_drug(drug_sim_feat, drug_feature_graph)
+            emb2_feat = self.FGCN_disease(disease_sim_feat, disease_feature_graph)
+            emb1 = torch.relu(self.drug_fusion(torch.cat([emb1_sim, emb1_feat], dim=1)))
+            emb2 = torch.relu(self.disease_fusion(torch.cat([emb2_sim, emb2_feat], dim=1)))
+            emb1 = F.dropout(emb1, p=self.dropout, training=self.training)
+            emb2 = F.dropout(emb2, p=self.dropout, training=self.training)
+        else:
+            emb1, emb2 = emb1_sim, emb2_sim
+        return emb1, emb2, emb1_sim, emb1_feat, emb2_sim, emb2_feat
+
+
+__all__ = ["GCMCLayer", "GCMCGraphConv", "HeteroGraphConv", "GraphConvolution", "GCN", "FGCN",
+           "dot_or_identity", "get_activation", "to_etype_name", "adjacency_csr", "DGMIError"]

@@ -1,0 +1,135 @@
+"""Multi-GPU sharding of the SpMM path: one process per GPU, RCCL over xGMI.
+
+The reference is single-device (train.py:459-463); this module exists only for the synthetic
+configs large enough to shard (BASELINE cfg 5).  SpMM is linear in the edge set, so any edge
+partition gives partial results that sum to the answer.  Two exchange forms are provided:
+
+``rows`` (default)  the edge partition is aligned to destination-row boundaries and balanced
+                    by nnz: each rank owns a contiguous row range and all in-edges of those
+                    rows.  Partial outputs are disjoint, so the sum degenerates to an
+                    **all-gather** of N_dst*F*4/P bytes per rank — no reduction traffic.
+                    The backward (A^T dY) uses the same construction on the reversed edges
+                    (partitioned by source range), so it is also local-SpMM + all-gather.
+``edges``           an arbitrary edge partition: every rank produces a full-height partial Y
+                    and the ranks **all-reduce** it (north_star's literal form).  xGMI is
+                    point-to-point (7 links per GPU), so a ring all-reduce of N_dst*F*4 bytes is
+                    single-link bound; kept for partitions that cannot be row-aligned.
+
+X (source features) is replicated on every rank, as the next layer needs all rows anyway.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def balanced_row_bounds(degree: torch.Tensor, parts: int) -> torch.Tensor:
+    """Contiguous row ranges with ~equal nnz: int64[parts+1], bounds[0]=0, bounds[-1]=n_rows."""
+    n = degree.shape[0]
+    csum = torch.cumsum(degree.to(torch.int64), 0)
+    total = int(csum[-1]) if n else 0
+    targets = torch.arange(1, parts, device=degree.device, dtype=torch.int64) * total // parts
+    cuts = torch.searchsorted(csum, targets, right=False) + 1 if n else targets
+    cuts = torch.clamp(cuts, 0, n)
+    bounds = torch.cat([torch.zeros(1, dtype=torch.int64, device=degree.device), cuts,
+                        torch.full((1,), n, dtype=torch.int64, device=degree.device)])
+    return torch.cummax(bounds, 0)[0]
+
+
+class RowShard:
+    """This rank's rows [lo, hi) of a relation: local CSR over all in-edges of those rows."""
+
+    def __init__(self, dst: torch.Tensor, src: torch.Tensor, n_dst: int, n_src: int,
+                 bounds: torch.Tensor, rank: int, vals: Optional[torch.Tensor] = None):
+        self.bounds = [int(b) for b in bounds.tolist()]
+        self.rank, self.world = rank, len(self.bounds) - 1
+        self.lo, self.hi = self.bounds[rank], self.bounds[rank + 1]
+        self.n_dst, self.n_src = int(n_dst), int(n_src)
+        mine = (dst >= self.lo) & (dst < self.hi)
+        self.local = ops.CSRGraph((dst[mine] - self.lo).to(torch.int32), src[mine].to(torch.int32),
+                                  self.hi - self.lo, n_src, vals=None if vals is None else vals[mine])
+        self.max_rows = max(self.bounds[i + 1] - self.bounds[i] for i in range(self.world))
+
+    @property
+    def nnz(self) -> int:
+        return self.local.nnz
+
+    def spmm_local(self, X, src_scale=None, dst_scale=None, out=None):
+        """Rows [lo, hi) of ``diag(dst_scale) A diag(src_scale) X``; scales are full-length."""
+        ds = None if dst_scale is None else dst_scale.reshape(-1)[self.lo:self.hi].contiguous()
+        return ops.spmm_csr_raw(self.local.indptr, self.local.indices, self.local.vals, X, src_scale, ds, out=out)
+
+    def gather_rows(self, y_local: torch.Tensor, group=None, out: Optional[torch.Tensor] = None,
+                    async_op: bool = False):
+        """All-gather the per-rank row blocks into the full (n_dst, F) result."""
+        F = y_local.shape[1]
+        even = all(self.bounds[i + 1] - self.bounds[i] == self.max_rows for i in range(self.world))
+        if even:
+            if out is None:
+                out = torch.empty((self.n_dst, F), dtype=y_local.dtype, device=y_local.device)
+            work = dist.all_gather_into_tensor(out, y_local.contiguous(), group=group, async_op=async_op)
+            return (out, work) if async_op else out
+        pad = torch.zeros((self.max_rows, F), dtype=y_local.dtype, device=y_local.device)
+        pad[: y_local.shape[0]] = y_local
+        buf = torch.empty((self.world * self.max_rows, F), dtype=y_local.dtype, device=y_local.device)
+        dist.all_gather_into_tensor(buf, pad, group=group)
+        if out is None:
+            out = torch.empty((self.n_dst, F), dtype=y_local.dtype, device=y_local.device)
+        for r in range(self.world):
+            n = self.bounds[r + 1] - self.bounds[r]
+            out[self.bounds[r]:self.bounds[r + 1]] = buf[r * self.max_rows: r * self.max_rows + n]
+        return (out, None) if async_op else out
+
+
+class ShardedRelation:
+    """A relation sharded over the process group, with autograd: forward = by-destination row
+    shard, backward = by-source row shard of the reversed edges; both end in an all-gather."""
+
+    def __init__(self, dst, src, n_dst, n_src, vals=None, group=None, rank=None, world=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.n_dst, self.n_src = int(n_dst), int(n_src)
+        deg_in = torch.bincount(dst.long(), minlength=n_dst)
+        deg_out = torch.bincount(src.long(), minlength=n_src)
+        self.fwd = RowShard(dst, src, n_dst, n_src, balanced_row_bounds(deg_in, self.world), self.rank, vals)
+        self.bwd = RowShard(src, dst, n_src, n_dst, balanced_row_bounds(deg_out, self.world), self.rank, vals)
+
+    def __call__(self, X, src_scale=None, dst_scale=None):
+        return _ShardedSpMM.apply(X, self, src_scale, dst_scale)
+
+
+class _ShardedSpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, rel: ShardedRelation, src_scale, dst_scale):
+        ctx.rel = rel
+        ctx.save_for_backward(src_scale, dst_scale)
+        return rel.fwd.gather_rows(rel.fwd.spmm_local(X, src_scale, dst_scale), rel.group)
+
+    @staticmethod
+    def backward(ctx, dY):
+        src_scale, dst_scale = ctx.saved_tensors
+        rel = ctx.rel
+        # dX = diag(src_scale) A^T diag(dst_scale) dY: rows = source nodes of this rank's range
+        dX = rel.bwd.gather_rows(rel.bwd.spmm_local(dY.contiguous(), dst_scale, src_scale), rel.group)
+        return dX, None, None, None
+
+
+class EdgeShard:
+    """Arbitrary edge partition + sum all-reduce of the full-height partial result."""
+
+    def __init__(self, dst, src, n_dst, n_src, vals=None, group=None):
+        self.group = group
+        self.local = ops.CSRGraph(dst.to(torch.int32), src.to(torch.int32), n_dst, n_src, vals=vals)
+
+    def spmm(self, X, src_scale=None, dst_scale=None):
+        # dst_scale is linear: apply it after the reduce (once), src_scale inside the kernel
+        y = ops.spmm_csr_raw(self.local.indptr, self.local.indices, self.local.vals, X, src_scale, None)
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+        if dst_scale is not None:
+            y = y * dst_scale.reshape(-1, 1)
+        return y

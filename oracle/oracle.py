@@ -99,7 +99,7 @@ def csr_from_coo(row, col, n_rows):
     return indptr, indices, eid
 
 
-def spmm_csr(indptr, indices, vals, X, src_scale=None, dst_scale=None, threads=1, acc="f32"):
+def spmm_csr(indptr, indices, vals, X, src_scale=None, dst_scale=None, threads=1, acc="f32", validate=True):
     """``Y = diag(dst_scale) A diag(src_scale) X`` over a CSR; ``vals=None`` is
     ``update_all(copy_u, sum)`` (layers.py:229-232), else ``th.spmm`` (layers.py:312).
     ``acc``: 'f32' (sequential fp32, CSR order), 'f64' (double), 'abs' (sum |terms|)."""
@@ -111,7 +111,7 @@ def spmm_csr(indptr, indices, vals, X, src_scale=None, dst_scale=None, threads=1
     dst_scale = _c(None if dst_scale is None else np.asarray(dst_scale).reshape(-1), np.float32)
     n_dst = indptr.shape[0] - 1
     F = X.shape[1]
-    if indices.size and (indices.min() < 0 or indices.max() >= X.shape[0]):
+    if validate and indices.size and (indices.min() < 0 or indices.max() >= X.shape[0]):
         raise ValueError("column id out of range")
     L = lib()
     if acc == "f32":

@@ -1,0 +1,46 @@
+"""Oracle-backed CPU stand-ins for the three ops, for HOST-LOGIC tests only.
+
+``-m "not gpu"`` tests exercise the drop-in modules' Python (weight composition, scaling and
+dropout placement, hetero sum, state_dict layout, caching, autograd wiring) on the build box,
+which has no GPU.  They monkeypatch ``dream_gnn_amd.ops`` with these functions explicitly; the
+product itself never does this and refuses CPU tensors.
+"""
+import contextlib
+
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+
+def csr_from_coo(row, col, n_rows, check_range=False):
+    indptr, indices, eid = O.csr_from_coo(row.cpu().numpy(), col.cpu().numpy(), int(n_rows))
+    return torch.from_numpy(indptr), torch.from_numpy(indices), torch.from_numpy(eid)
+
+
+def gather_f32(values, perm):
+    return values[perm.long()].contiguous()
+
+
+def spmm_csr_raw(indptr, indices, vals, X, src_scale=None, dst_scale=None, out=None):
+    n = lambda t: None if t is None else t.detach().cpu().numpy()
+    y = O.spmm_csr(n(indptr), n(indices), n(vals), np.ascontiguousarray(n(X)), n(src_scale), n(dst_scale))
+    y = torch.from_numpy(y)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+@contextlib.contextmanager
+def patched():
+    from dream_gnn_amd import ops
+
+    saved = {k: getattr(ops, k) for k in ("csr_from_coo", "gather_f32", "spmm_csr_raw", "_require_device")}
+    ops.csr_from_coo, ops.gather_f32, ops.spmm_csr_raw = csr_from_coo, gather_f32, spmm_csr_raw
+    ops._require_device = lambda *ts: next((t.device for t in ts if t is not None), None)
+    try:
+        yield
+    finally:
+        for k, v in saved.items():
+            setattr(ops, k, v)

@@ -1,0 +1,86 @@
+"""The C-ABI library loads on the build box and exports exactly what include/dgmi.h declares.
+No compute call is made here (no GPU): only version / string / argument-validation paths that
+return before any HIP launch."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "dgmi.h")).read()
+    return sorted(set(re.findall(r"DGMI_API\s+[\w\s\*]+?\b(dgmi_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    assert _declared() == ["dgmi_abi_version", "dgmi_csr_from_coo_i32", "dgmi_device_ok", "dgmi_gather_f32",
+                           "dgmi_spmm_csr_f32", "dgmi_status_string"]
+
+
+def test_library_exports_every_declared_symbol():
+    from dream_gnn_amd import _lib
+
+    for name in _declared():
+        assert hasattr(_lib.lib, name), name
+        assert name in _lib.SIGNATURES, "ctypes binding missing for " + name
+    assert sorted(_lib.SIGNATURES) == _declared()
+
+
+def test_version_and_status_strings():
+    from dream_gnn_amd import _lib
+
+    text = open(os.path.join(ROOT, "include", "dgmi.h")).read()
+    assert _lib.lib.dgmi_abi_version() == int(re.search(r"#define DGMI_ABI_VERSION (\d+)", text).group(1))
+    assert _lib.lib.dgmi_status_string(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5):
+        assert len(_lib.lib.dgmi_status_string(code)) > 3
+    assert b"unknown" in _lib.lib.dgmi_status_string(-99)
+
+
+def test_argument_validation_returns_codes_without_a_gpu():
+    from dream_gnn_amd import _lib
+
+    L = _lib.lib
+    need = ctypes.c_size_t(0)
+    assert L.dgmi_csr_from_coo_i32(None, None, -1, 4, None, None, None, None, ctypes.byref(need), None) == -1
+    assert L.dgmi_csr_from_coo_i32(None, None, 1, 4, None, None, None, None, None, None) == -1
+    assert L.dgmi_csr_from_coo_i32(None, None, 2 ** 31, 4, None, None, None, None, ctypes.byref(need), None) == -2
+    assert L.dgmi_spmm_csr_f32(None, None, None, None, 4, None, None, None, 4, -1, 1, 4, None) == -1
+    assert L.dgmi_spmm_csr_f32(None, None, None, None, 4, None, None, None, 4, 2, 2, 4, None) == -1  # null indptr/Y
+    assert L.dgmi_spmm_csr_f32(None, None, None, None, 4, None, None, None, 4, 0, 0, 4, None) == 0   # empty problem
+    assert L.dgmi_spmm_csr_f32(16, 16, None, 16, 2, None, None, 32, 4, 2, 2, 4, None) == -1          # ldx < F
+    assert L.dgmi_spmm_csr_f32(16, 16, None, 64, 4, None, None, 64, 4, 2, 2, 4, None) == -1          # Y aliases X
+    assert L.dgmi_gather_f32(None, None, -3, None, None) == -1
+    assert L.dgmi_gather_f32(None, None, 0, None, None) == 0
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+
+    from dream_gnn_amd import ops
+
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        ops.csr_from_coo(torch.zeros(3, dtype=torch.int32), torch.zeros(3, dtype=torch.int32), 2)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        ops.CSRGraph(torch.zeros(3, dtype=torch.int32), torch.zeros(3, dtype=torch.int32), 2, 2)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from dream_gnn_amd import _lib
+
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libdgmi.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib._load()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "dream_gnn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "libdgmi_oracle" not in src, f
