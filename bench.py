@@ -124,6 +124,19 @@ def run_step(ops, comm_stream, record):
         cur.wait_stream(comm_stream)
 
 
+def host_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box gives a 1-GPU job 16 of the host's 256 hardware threads)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(ops, budget_s=12.0):
     """The CPU oracle (OpenMP restatement of DGL's row-parallel copy_u->sum) on the first GCMC op."""
     from oracle import oracle as O
@@ -133,7 +146,7 @@ def cpu_baseline(ops, budget_s=12.0):
     g = op.shard.local
     indptr, indices = g.indptr.cpu().numpy(), g.indices.cpu().numpy()
     X, ss, ds = op.X.cpu().numpy(), op.ss.cpu().numpy(), op.ds[op.shard.lo:op.shard.hi].cpu().numpy()
-    threads = min(len(os.sched_getaffinity(0)), O.max_threads())
+    threads = min(host_cores(), O.max_threads())
     O.spmm_csr(indptr[:1025], indices, None, X, ss, ds[:1024], threads=threads)  # touch / warm
     times = []
     t_end = time.perf_counter() + budget_s
