@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 F = 128
 BASE_DRUG, BASE_DIS, BASE_EDGES, KNN_K = 100_000, 50_000, 10_000_000, 64
-DOMINANT = "spmm_csr_vec4_kernel<32,false,true,true>"  # unweighted, src+dst scale, F=128
+DOMINANT = "spmm_csr_vec4_kernel<32,false,true,true,true>"  # LPR=32 (F=128), unweighted, src+dst scale, planned
 
 
 def algorithmic_bytes(nnz, n_rows, weighted, n_scales_src=0, n_scales_dst=0):

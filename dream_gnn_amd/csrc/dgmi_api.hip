@@ -42,17 +42,17 @@ DGMI_API int dgmi_device_ok(void) {
 }
 
 DGMI_API int dgmi_csr_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E, int64_t n_rows,
-                          int32_t* indptr, int32_t* indices, int32_t* eid, void* workspace,
+                          int64_t n_cols, int32_t* indptr, int32_t* indices, int32_t* eid, void* workspace,
                           size_t* workspace_bytes, dgmi_stream_t stream) {
   if (E < 0 || n_rows < 0 || workspace_bytes == nullptr) return DGMI_ERR_INVALID_ARG;
-  if (E > INT32_MAX || n_rows >= INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (E > INT32_MAX || n_rows >= INT32_MAX || n_cols >= INT32_MAX) return DGMI_ERR_TOO_LARGE;
   if (workspace != nullptr) {
     if (indptr == nullptr) return DGMI_ERR_INVALID_ARG;
     if (E > 0 && (row == nullptr || col == nullptr || indices == nullptr || eid == nullptr))
       return DGMI_ERR_INVALID_ARG;
   }
   size_t need = 0;
-  hipError_t err = dgmi::csr_from_coo_i32(row, col, E, n_rows, indptr, indices, eid, nullptr,
+  hipError_t err = dgmi::csr_from_coo_i32(row, col, E, n_rows, n_cols, indptr, indices, eid, nullptr,
                                           &need, as_stream(stream));
   if (err != hipSuccess) return DGMI_ERR_LAUNCH;
   if (workspace == nullptr) {
@@ -60,7 +60,7 @@ DGMI_API int dgmi_csr_from_coo_i32(const int32_t* row, const int32_t* col, int64
     return DGMI_OK;
   }
   if (*workspace_bytes < need) return DGMI_ERR_WORKSPACE;
-  return from_hip(dgmi::csr_from_coo_i32(row, col, E, n_rows, indptr, indices, eid, workspace,
+  return from_hip(dgmi::csr_from_coo_i32(row, col, E, n_rows, n_cols, indptr, indices, eid, workspace,
                                          workspace_bytes, as_stream(stream)));
 }
 
@@ -77,7 +77,76 @@ DGMI_API int dgmi_spmm_csr_f32(const int32_t* indptr, const int32_t* indices, co
   // graph may pass NULL for them; X may be NULL only when there is no source node.
   if (X == nullptr && n_src > 0) return DGMI_ERR_INVALID_ARG;
   if (static_cast<const void*>(X) == static_cast<const void*>(Y)) return DGMI_ERR_INVALID_ARG;
-  dgmi::SpmmArgs a{indptr, indices, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F};
+  dgmi::SpmmArgs a{indptr, indices, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F,
+                   nullptr, 0, 0, nullptr, 0};
+  return from_hip(dgmi::spmm_csr_f32(a, as_stream(stream)));
+}
+
+DGMI_API int32_t dgmi_spmm_default_chunk(int64_t n_rows, int64_t nnz) {
+  // Aim for >= 4 waves on each of the 1024 SIMDs, never cut below one id batch (64) and
+  // never above 512 edges (a 512-edge chunk at F=128 is 256 KiB of gathers: long enough
+  // to amortise the wave's prologue, short enough to balance).
+  (void)n_rows;
+  int64_t c = (nnz / 4096 + 63) / 64 * 64;
+  if (c < 64) c = 64;
+  if (c > 512) c = 512;
+  return (int32_t)c;
+}
+
+static bool chunk_ok(int32_t chunk) { return chunk >= 16 && chunk <= 65536; }
+
+DGMI_API size_t dgmi_spmm_plan_bytes(int64_t n_rows, int64_t nnz, int32_t chunk) {
+  if (n_rows < 0 || nnz < 0 || !chunk_ok(chunk)) return 0;
+  return dgmi::plan_bytes(n_rows, nnz, chunk);
+}
+
+DGMI_API size_t dgmi_spmm_partials_bytes(int64_t nnz, int32_t chunk, int64_t F) {
+  if (nnz < 0 || F < 0 || !chunk_ok(chunk)) return 0;
+  const size_t ldp = (size_t)((F + 3) / 4 * 4);
+  const size_t b = (size_t)dgmi::plan_slots_cap(nnz, chunk) * ldp * sizeof(float);
+  return b < 16 ? 16 : b;
+}
+
+DGMI_API int dgmi_spmm_plan_build(const int32_t* indptr, int64_t n_rows, int64_t nnz, int32_t chunk,
+                                  void* plan, size_t plan_bytes, void* workspace,
+                                  size_t* workspace_bytes, dgmi_stream_t stream) {
+  if (n_rows < 0 || nnz < 0 || !chunk_ok(chunk) || workspace_bytes == nullptr)
+    return DGMI_ERR_INVALID_ARG;
+  if (n_rows >= INT32_MAX || nnz > INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  size_t need = 0;
+  if (dgmi::spmm_plan_build(indptr, n_rows, nnz, chunk, nullptr, nullptr, &need, as_stream(stream)) !=
+      hipSuccess)
+    return DGMI_ERR_LAUNCH;
+  if (workspace == nullptr) {
+    *workspace_bytes = need;
+    return DGMI_OK;
+  }
+  if (plan == nullptr || (indptr == nullptr && n_rows > 0)) return DGMI_ERR_INVALID_ARG;
+  if (*workspace_bytes < need || plan_bytes < dgmi::plan_bytes(n_rows, nnz, chunk))
+    return DGMI_ERR_WORKSPACE;
+  return from_hip(dgmi::spmm_plan_build(indptr, n_rows, nnz, chunk, static_cast<int32_t*>(plan),
+                                        workspace, workspace_bytes, as_stream(stream)));
+}
+
+DGMI_API int dgmi_spmm_csr_planned_f32(const int32_t* indptr, const int32_t* indices,
+                                       const float* vals, const float* X, int64_t ldx,
+                                       const float* src_scale, const float* dst_scale, float* Y,
+                                       int64_t ldy, int64_t n_dst, int64_t n_src, int64_t F,
+                                       int64_t nnz, int32_t chunk, const void* plan, void* partials,
+                                       size_t partials_bytes, dgmi_stream_t stream) {
+  if (n_dst < 0 || n_src < 0 || F < 0 || nnz < 0 || !chunk_ok(chunk)) return DGMI_ERR_INVALID_ARG;
+  if (n_dst >= INT32_MAX || n_src >= INT32_MAX || F > INT32_MAX || nnz > INT32_MAX)
+    return DGMI_ERR_TOO_LARGE;
+  if (n_dst == 0 || F == 0) return DGMI_OK;
+  if (indptr == nullptr || Y == nullptr || plan == nullptr || partials == nullptr)
+    return DGMI_ERR_INVALID_ARG;
+  if (ldx < F || ldy < F) return DGMI_ERR_INVALID_ARG;
+  if (X == nullptr && n_src > 0) return DGMI_ERR_INVALID_ARG;
+  if (static_cast<const void*>(X) == static_cast<const void*>(Y)) return DGMI_ERR_INVALID_ARG;
+  if (partials_bytes < dgmi_spmm_partials_bytes(nnz, chunk, F)) return DGMI_ERR_WORKSPACE;
+  dgmi::SpmmArgs a{indptr, indices, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F,
+                   static_cast<const int32_t*>(plan), nnz, chunk, static_cast<float*>(partials),
+                   (F + 3) / 4 * 4};
   return from_hip(dgmi::spmm_csr_f32(a, as_stream(stream)));
 }
 

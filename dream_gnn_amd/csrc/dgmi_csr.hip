@@ -6,7 +6,7 @@
 // th.spmm (layers.py:312) for the shuffled COO of augmentation.py:117-124.
 //
 // Pipeline (all on `stream`, no host sync, no atomics -> bit-exact & reproducible):
-//   1. iota + range check : tmp_eid[e] = e ; flag |= row[e] outside [0, n_rows)
+//   1. iota + range check : tmp_eid[e] = e ; flag |= row[e] outside [0, n_rows) or col[e] outside [0, n_cols)
 //   2. stable LSD radix sort of (row, e) pairs on the low ceil(log2 n_rows) bits
 //      — rocPRIM's device radix sort (a plain library primitive; stability is
 //      what makes eid the original order inside a row)
@@ -28,7 +28,8 @@ namespace {
 constexpr int kBlock = 256;
 
 __global__ __launch_bounds__(kBlock) void iota_check_kernel(const int32_t* __restrict__ row,
-                                                            int64_t E, int32_t n_rows,
+                                                            const int32_t* __restrict__ col,
+                                                            int64_t E, int32_t n_rows, int32_t n_cols,
                                                             int32_t* __restrict__ tmp_eid,
                                                             int32_t* __restrict__ flag) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -37,6 +38,10 @@ __global__ __launch_bounds__(kBlock) void iota_check_kernel(const int32_t* __res
     tmp_eid[e] = (int32_t)e;
     const int32_t r = row[e];
     bad |= (r < 0) | (r >= n_rows);
+    if (n_cols > 0) {
+      const int32_t c = col[e];
+      bad |= (c < 0) | (c >= n_cols);
+    }
   }
   if (bad) *flag = 1;  // benign race: every writer stores the same value
 }
@@ -84,7 +89,7 @@ inline int bits_for(int64_t n_rows) {
 }  // namespace
 
 hipError_t csr_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
-                            int64_t n_rows, int32_t* indptr, int32_t* indices,
+                            int64_t n_rows, int64_t n_cols, int32_t* indptr, int32_t* indices,
                             int32_t* eid, void* workspace, size_t* workspace_bytes,
                             hipStream_t s) {
   const int end_bit = bits_for(n_rows);
@@ -116,8 +121,8 @@ hipError_t csr_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
   hipError_t err = hipMemsetAsync(flag, 0, 256, s);
   if (err != hipSuccess) return err;
   if (E > 0) {
-    hipLaunchKernelGGL(iota_check_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, row, E,
-                       (int32_t)n_rows, tmp_eid, flag);
+    hipLaunchKernelGGL(iota_check_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, row, col, E,
+                       (int32_t)n_rows, (int32_t)n_cols, tmp_eid, flag);
     err = rocprim::radix_sort_pairs(sort_tmp, sort_bytes, reinterpret_cast<const uint32_t*>(row),
                                     reinterpret_cast<uint32_t*>(keys_out),
                                     static_cast<const int32_t*>(tmp_eid), eid, (size_t)E, 0u,

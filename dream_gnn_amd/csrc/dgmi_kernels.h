@@ -8,6 +8,32 @@
 
 namespace dgmi {
 
+// ---- SpMM plan (dgmi_plan.hip): int32 words on the device --------------------------------
+//   [0, kPlanHeaderWords)                      header
+//   then items_cap x int4 {row, start, end, slot}   one per wave of the main launch;
+//                                                  slot < 0 -> the wave owns the whole row
+//   then long_cap  x int4 {row, slot0, nchunks, 0}  rows cut into > 1 chunk (reduce pass)
+constexpr int kPlanHeaderWords = 16;
+constexpr int kPlanNumItems = 0;
+constexpr int kPlanNumLong = 1;
+constexpr int kPlanNumSlots = 2;
+constexpr int kPlanChunk = 3;
+
+// Upper bounds the host can compute without reading the degree distribution back:
+// sum_r max(1, ceil(deg_r / chunk)) <= n_rows + nnz / chunk;  rows with deg > chunk number
+// at most nnz / (chunk + 1);  their chunks at most nnz / chunk + #long rows.
+inline int64_t plan_items_cap(int64_t n_rows, int64_t nnz, int64_t chunk) {
+  return n_rows + nnz / chunk;
+}
+inline int64_t plan_long_cap(int64_t nnz, int64_t chunk) { return nnz / (chunk + 1); }
+inline int64_t plan_slots_cap(int64_t nnz, int64_t chunk) {
+  return nnz / chunk + plan_long_cap(nnz, chunk);
+}
+inline size_t plan_bytes(int64_t n_rows, int64_t nnz, int64_t chunk) {
+  return sizeof(int32_t) *
+         (size_t)(kPlanHeaderWords + 4 * (plan_items_cap(n_rows, nnz, chunk) + plan_long_cap(nnz, chunk)));
+}
+
 struct SpmmArgs {
   const int32_t* indptr;
   const int32_t* indices;
@@ -21,14 +47,24 @@ struct SpmmArgs {
   int64_t n_dst;
   int64_t n_src;
   int64_t F;
+  // planned launch only (plan == nullptr: one wave per row)
+  const int32_t* plan;
+  int64_t nnz;
+  int64_t chunk;
+  float* partials;
+  int64_t ldp;
 };
 
 // Y = diag(dst_scale) A diag(src_scale) X   (dgmi_spmm.hip)
 hipError_t spmm_csr_f32(const SpmmArgs& a, hipStream_t s);
 
+// Builds the plan for `indptr` (dgmi_plan.hip).  workspace == nullptr: size query only.
+hipError_t spmm_plan_build(const int32_t* indptr, int64_t n_rows, int64_t nnz, int64_t chunk,
+                           int32_t* plan, void* workspace, size_t* workspace_bytes, hipStream_t s);
+
 // Stable COO->CSR (dgmi_csr.hip).  workspace == nullptr: size query only.
 hipError_t csr_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
-                            int64_t n_rows, int32_t* indptr, int32_t* indices,
+                            int64_t n_rows, int64_t n_cols, int32_t* indptr, int32_t* indices,
                             int32_t* eid, void* workspace, size_t* workspace_bytes,
                             hipStream_t s);
 

@@ -9,19 +9,24 @@
 // kernel moves one source row (4*F bytes) and 4 (+4) bytes of index (value);
 // arithmetic intensity is 0.25-0.5 flop/B, so there is nothing for MFMA here.
 // Design for CDNA4:
-//   * one 64-lane wave owns one destination row (segmented reduce = the wave's
-//     own registers; no atomics, fixed summation order -> bitwise reproducible);
-//   * a source row is read with 16-B loads: LPR = F/4 lanes cover a row, so a
-//     wave-instruction carries 64/LPR whole rows (F=128: 2 rows x 512 B = 1 KiB,
-//     the widest coalesced access the hardware has);
-//   * the row's column ids (and values) are read 64 at a time, one per lane,
-//     coalesced, one batch ahead of use, and handed to the row loads by
+//   * one 64-lane wave owns one *segment* of one destination row (segmented
+//     reduce = the wave's own registers; no atomics, fixed summation order ->
+//     bitwise reproducible).  Unplanned launch: segment = whole row.  Planned
+//     launch (dgmi_plan.hip): rows longer than `chunk` edges are cut into
+//     chunks so that a power-law degree distribution or a small dense graph
+//     still fills the chip; chunk partials are summed in chunk order by a
+//     second kernel;
+//   * a source row is read with 16-B loads: LPR lanes cover (a tile of) a row,
+//     so a wave-instruction carries 64/LPR whole rows (F=128: 2 rows x 512 B =
+//     1 KiB, the widest coalesced access the hardware has);
+//   * the segment's column ids (and values) are read 64 at a time, one per
+//     lane, coalesced, one batch ahead of use, and handed to the row loads by
 //     ds_bpermute; 8 row loads are kept in flight per wave (8 KiB at F=128,
 //     x 16-32 waves per CU) to cover Infinity-Cache / HBM latency;
 //   * the 64/LPR partial sums are combined with xor-shuffles and written with
 //     one coalesced 16-B-per-lane store, scaled by dst_scale.
 // Feature widths that are not a multiple of 4 (layer-0's 341, layers.py:55-57)
-// or rows that are not 16-B aligned take the dword kernel below.
+// or rows that are not 16-B aligned take the dword kernels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -39,6 +44,20 @@ __device__ __forceinline__ float4 ld4(const float* p) {
   return *reinterpret_cast<const float4*>(p);
 }
 
+__device__ __forceinline__ void tree_sum(float4 (&v)[kUnroll], int n_live) {
+  (void)n_live;
+#pragma unroll
+  for (int span = 1; span < kUnroll; span <<= 1) {
+#pragma unroll
+    for (int u = 0; u + span < kUnroll; u += 2 * span) {
+      v[u].x += v[u + span].x;
+      v[u].y += v[u + span].y;
+      v[u].z += v[u + span].z;
+      v[u].w += v[u + span].w;
+    }
+  }
+}
+
 // One batch of up to 64 edges whose ids/weights sit one-per-lane in
 // (my_idx, my_w).  FULL: all 64 are valid, no predication in the loop.
 template <int LPR, bool WEIGHTED, bool FULL>
@@ -47,45 +66,35 @@ __device__ __forceinline__ void gather_batch(const float* __restrict__ Xc, int64
                                              float4& acc) {
   constexpr int EPI = kWave / LPR;  // edges per wave-instruction
   constexpr int STEPS = kWave / EPI;
-  static_assert(STEPS % kUnroll == 0 || STEPS < kUnroll, "unroll must divide steps");
-  constexpr int U = STEPS < kUnroll ? STEPS : kUnroll;
+  static_assert(STEPS % kUnroll == 0, "unroll must divide steps");
 #pragma unroll 1
-  for (int s = 0; s < STEPS; s += U) {
+  for (int s = 0; s < STEPS; s += kUnroll) {
     if (!FULL && s * EPI >= n) break;
-    float4 v[U];
-    float w[U];
+    float4 v[kUnroll];
+    float w[kUnroll];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < kUnroll; ++u) {
       const int e = (s + u) * EPI + sub;
       const int idx = __shfl(my_idx, e, kWave);
       if (WEIGHTED) w[u] = __shfl(my_w, e, kWave);
-      // Lanes past the end of a tail batch carry idx = first id of the batch
+      // Lanes past the end of a tail batch carry the first id of the batch
       // (a valid row) and are zeroed below, so no load leaves the matrix.
       v[u] = ld4(Xc + (int64_t)idx * ldx);
       if (!FULL && e >= n) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // Sum the U rows as a balanced tree and add the result to the running sum: the same
-    // number of adds as a chain, U-way ILP, and the long chain shrinks U-fold (rounding
-    // error of a 60k-edge row stays inside 1e-5 relative).
     if (WEIGHTED) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < kUnroll; ++u) {
         v[u].x *= w[u];
         v[u].y *= w[u];
         v[u].z *= w[u];
         v[u].w *= w[u];
       }
     }
-#pragma unroll
-    for (int span = 1; span < U; span <<= 1) {
-#pragma unroll
-      for (int u = 0; u + span < U; u += 2 * span) {
-        v[u].x += v[u + span].x;
-        v[u].y += v[u + span].y;
-        v[u].z += v[u + span].z;
-        v[u].w += v[u + span].w;
-      }
-    }
+    // Balanced tree over the 8 rows, then one add into the running sum: same
+    // add count as a chain, 8-way ILP, and the long dependent chain (and its
+    // rounding growth on 10^4..10^6-edge rows) shrinks 8-fold.
+    tree_sum(v, kUnroll);
     acc.x += v[0].x;
     acc.y += v[0].y;
     acc.z += v[0].z;
@@ -93,28 +102,17 @@ __device__ __forceinline__ void gather_batch(const float* __restrict__ Xc, int64
   }
 }
 
-// grid.x = ceil(n_dst / 4), grid.y = ceil(F / (4*LPR)); block = 256 (4 waves).
-template <int LPR, bool HAS_VALS, bool HAS_SS, bool HAS_DS>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_csr_vec4_kernel(
-    const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
-    const float* __restrict__ vals, const float* __restrict__ X, int64_t ldx,
-    const float* __restrict__ src_scale, const float* __restrict__ dst_scale,
-    float* __restrict__ Y, int64_t ldy, int64_t n_dst, int F) {
+// Sum of edges [start, end) of one row over this lane's 4 columns; the result
+// is complete (all 64/LPR lane groups combined) in every lane.
+template <int LPR, bool HAS_VALS, bool HAS_SS>
+__device__ __forceinline__ float4 segment_vec4(const int32_t* __restrict__ indices,
+                                               const float* __restrict__ vals,
+                                               const float* __restrict__ src_scale,
+                                               const float* __restrict__ Xc, int64_t ldx,
+                                               int start, int end, int lane) {
   constexpr bool WEIGHTED = HAS_VALS || HAS_SS;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  if (row >= n_dst) return;  // wave-uniform
   const int sub = lane / LPR;
-  int col = ((int)blockIdx.y * LPR + (lane % LPR)) * 4;
-  const bool col_ok = col < F;
-  if (!col_ok) col = 0;  // keep the loads in bounds; result discarded
-  const float* Xc = X + col;
-
-  const int start = indptr[row];
-  const int end = indptr[row + 1];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-
   // software pipeline: ids (and weights) of batch b+1 are requested before the
   // row loads of batch b are issued.
   int nxt_idx = 0;
@@ -149,7 +147,6 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_csr_vec4_kernel(
     else
       gather_batch<LPR, WEIGHTED, false>(Xc, ldx, my_idx, my_w, n, sub, acc);
   }
-
   // combine the 64/LPR partial rows (fixed order -> deterministic)
 #pragma unroll
   for (int off = LPR; off < kWave; off <<= 1) {
@@ -158,50 +155,26 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_csr_vec4_kernel(
     acc.z += __shfl_xor(acc.z, off, kWave);
     acc.w += __shfl_xor(acc.w, off, kWave);
   }
-  if (sub == 0 && col_ok) {
-    if (HAS_DS) {
-      const float d = dst_scale[row];
-      acc.x *= d;
-      acc.y *= d;
-      acc.z *= d;
-      acc.w *= d;
-    }
-    *reinterpret_cast<float4*>(Y + row * ldy + col) = acc;
-  }
+  return acc;
 }
 
-// Any F, any alignment: lanes across 64 consecutive columns, one dword each;
-// grid.y = ceil(F/64).  Used for F % 4 != 0 (341) and unaligned views.
-template <bool HAS_VALS, bool HAS_SS, bool HAS_DS>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_csr_dword_kernel(
-    const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
-    const float* __restrict__ vals, const float* __restrict__ X, int64_t ldx,
-    const float* __restrict__ src_scale, const float* __restrict__ dst_scale,
-    float* __restrict__ Y, int64_t ldy, int64_t n_dst, int F) {
+// Same for one column per lane (any F, any alignment).
+template <bool HAS_VALS, bool HAS_SS>
+__device__ __forceinline__ float segment_dword(const int32_t* __restrict__ indices,
+                                               const float* __restrict__ vals,
+                                               const float* __restrict__ src_scale,
+                                               const float* __restrict__ Xc, int64_t ldx,
+                                               int start, int end, int lane) {
   constexpr bool WEIGHTED = HAS_VALS || HAS_SS;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-  if (row >= n_dst) return;
-  int col = (int)blockIdx.y * kWave + lane;
-  const bool col_ok = col < F;
-  if (!col_ok) col = 0;
-  const float* Xc = X + col;
-  const int start = indptr[row];
-  const int end = indptr[row + 1];
   float acc = 0.f;
   for (int base = start; base < end; base += kWave) {
     const int n = min(kWave, end - base);
-    int my_idx = 0;
+    const int q = lane < n ? base + lane : base;
+    const int my_idx = indices[q];
     float my_w = 0.f;
-    {
-      const int q = lane < n ? base + lane : base;
-      my_idx = indices[q];
-      if (WEIGHTED) {
-        float w = HAS_VALS ? vals[q] : 1.f;
-        if (HAS_SS) w *= src_scale[my_idx];
-        my_w = w;
-      }
+    if (WEIGHTED) {
+      my_w = HAS_VALS ? vals[q] : 1.f;
+      if (HAS_SS) my_w *= src_scale[my_idx];
     }
 #pragma unroll 1
     for (int s = 0; s < n; s += kUnroll) {
@@ -226,22 +199,151 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_csr_dword_kernel(
       acc += v[0];
     }
   }
+  return acc;
+}
+
+struct Segment {
+  int64_t row;
+  int start, end, slot;  // slot < 0: final result -> Y[row]; else partial -> P[slot]
+};
+
+// PLANNED = false: wave w handles row w whole.  PLANNED = true: wave w handles
+// item w of the plan (dgmi_plan.hip): {row, start, end, slot}.
+template <bool PLANNED>
+__device__ __forceinline__ bool fetch_segment(const int32_t* __restrict__ indptr,
+                                              const int32_t* __restrict__ plan, int64_t n_dst,
+                                              Segment& sg) {
+  const int wave = threadIdx.x >> 6;
+  const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (!PLANNED) {
+    if (w >= n_dst) return false;
+    sg.row = w;
+    sg.start = indptr[w];
+    sg.end = indptr[w + 1];
+    sg.slot = -1;
+    return true;
+  }
+  if (w >= plan[kPlanNumItems]) return false;
+  const int4 it = reinterpret_cast<const int4*>(plan + kPlanHeaderWords)[w];
+  sg.row = it.x;
+  sg.start = it.y;
+  sg.end = it.z;
+  sg.slot = it.w;
+  return true;
+}
+
+// grid.x = ceil(#segments / 4), grid.y = ceil(F / (4*LPR)); block = 256 (4 waves).
+template <int LPR, bool HAS_VALS, bool HAS_SS, bool HAS_DS, bool PLANNED>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_csr_vec4_kernel(
+    const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const float* __restrict__ vals, const float* __restrict__ X, int64_t ldx,
+    const float* __restrict__ src_scale, const float* __restrict__ dst_scale,
+    float* __restrict__ Y, int64_t ldy, int64_t n_dst, int F,
+    const int32_t* __restrict__ plan, float* __restrict__ P, int64_t ldp) {
+  Segment sg;
+  if (!fetch_segment<PLANNED>(indptr, plan, n_dst, sg)) return;  // wave-uniform
+  const int lane = threadIdx.x & (kWave - 1);
+  int col = ((int)blockIdx.y * LPR + (lane % LPR)) * 4;
+  const bool col_ok = col < F;
+  if (!col_ok) col = 0;  // keep the loads in bounds; result discarded
+  float4 acc = segment_vec4<LPR, HAS_VALS, HAS_SS>(indices, vals, src_scale, X + col, ldx,
+                                                   sg.start, sg.end, lane);
+  if (lane < LPR && col_ok) {
+    if (PLANNED && sg.slot >= 0) {
+      *reinterpret_cast<float4*>(P + (int64_t)sg.slot * ldp + col) = acc;
+    } else {
+      if (HAS_DS) {
+        const float d = dst_scale[sg.row];
+        acc.x *= d;
+        acc.y *= d;
+        acc.z *= d;
+        acc.w *= d;
+      }
+      *reinterpret_cast<float4*>(Y + sg.row * ldy + col) = acc;
+    }
+  }
+}
+
+// Any F, any alignment: lanes across 64 consecutive columns, one dword each;
+// grid.y = ceil(F/64).
+template <bool HAS_VALS, bool HAS_SS, bool HAS_DS, bool PLANNED>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_csr_dword_kernel(
+    const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+    const float* __restrict__ vals, const float* __restrict__ X, int64_t ldx,
+    const float* __restrict__ src_scale, const float* __restrict__ dst_scale,
+    float* __restrict__ Y, int64_t ldy, int64_t n_dst, int F,
+    const int32_t* __restrict__ plan, float* __restrict__ P, int64_t ldp) {
+  Segment sg;
+  if (!fetch_segment<PLANNED>(indptr, plan, n_dst, sg)) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  int col = (int)blockIdx.y * kWave + lane;
+  const bool col_ok = col < F;
+  if (!col_ok) col = 0;
+  float acc = segment_dword<HAS_VALS, HAS_SS>(indices, vals, src_scale, X + col, ldx,
+                                              sg.start, sg.end, lane);
   if (col_ok) {
+    if (PLANNED && sg.slot >= 0) {
+      P[(int64_t)sg.slot * ldp + col] = acc;
+    } else {
+      if (HAS_DS) acc *= dst_scale[sg.row];
+      Y[sg.row * ldy + col] = acc;
+    }
+  }
+}
+
+// Second pass of a planned launch: Y[row] = dst_scale[row] * sum_k P[slot0 + k], chunks
+// added in chunk order (tree over groups of 8, then a chain) -> deterministic.
+// One wave per (long row, 64-column tile).
+template <bool HAS_DS>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_reduce_partials_kernel(
+    const int32_t* __restrict__ plan, const float* __restrict__ P, int64_t ldp,
+    const float* __restrict__ dst_scale, float* __restrict__ Y, int64_t ldy, int F,
+    int64_t items_cap) {
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int col = (int)blockIdx.y * kWave + lane;
+  if (col >= F) return;
+  const int64_t n_long = plan[kPlanNumLong];
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  // grid-stride over the long rows: the host sizes the grid from an upper bound (it never
+  // reads the plan back), so with no long row every wave leaves here at once.
+  for (int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave; w < n_long; w += stride) {
+    const int4 lr = reinterpret_cast<const int4*>(plan + kPlanHeaderWords)[items_cap + w];
+    const int64_t row = lr.x;
+    const int slot0 = lr.y, n = lr.z;
+    const float* p = P + (int64_t)slot0 * ldp + col;
+    float acc = 0.f;
+    int k = 0;
+    for (; k + kUnroll <= n; k += kUnroll) {
+      float v[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) v[u] = p[(int64_t)(k + u) * ldp];
+#pragma unroll
+      for (int span = 1; span < kUnroll; span <<= 1) {
+#pragma unroll
+        for (int u = 0; u + span < kUnroll; u += 2 * span) v[u] += v[u + span];
+      }
+      acc += v[0];
+    }
+    for (; k < n; ++k) acc += p[(int64_t)k * ldp];
     if (HAS_DS) acc *= dst_scale[row];
     Y[row * ldy + col] = acc;
   }
 }
 
-template <int LPR>
-hipError_t launch_vec4(const SpmmArgs& a, hipStream_t s) {
-  dim3 grid((unsigned)((a.n_dst + kWavesPerBlock - 1) / kWavesPerBlock),
-            (unsigned)((a.F + 4 * LPR - 1) / (4 * LPR)));
+inline unsigned blocks_for(int64_t waves) {
+  return (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+}
+
+template <int LPR, bool PLANNED>
+hipError_t launch_vec4(const SpmmArgs& a, int64_t segments, hipStream_t s) {
+  dim3 grid(blocks_for(segments), (unsigned)((a.F + 4 * LPR - 1) / (4 * LPR)));
   dim3 block(kWave * kWavesPerBlock);
   const int key = (a.vals ? 4 : 0) | (a.src_scale ? 2 : 0) | (a.dst_scale ? 1 : 0);
-#define DGMI_LAUNCH(V, S, D)                                                         \
-  hipLaunchKernelGGL((spmm_csr_vec4_kernel<LPR, V, S, D>), grid, block, 0, s,         \
-                     a.indptr, a.indices, a.vals, a.X, a.ldx, a.src_scale,            \
-                     a.dst_scale, a.Y, a.ldy, a.n_dst, (int)a.F)
+#define DGMI_LAUNCH(V, S, D)                                                              \
+  hipLaunchKernelGGL((spmm_csr_vec4_kernel<LPR, V, S, D, PLANNED>), grid, block, 0, s,     \
+                     a.indptr, a.indices, a.vals, a.X, a.ldx, a.src_scale, a.dst_scale,    \
+                     a.Y, a.ldy, a.n_dst, (int)a.F, a.plan, a.partials, a.ldp)
   switch (key) {
     case 0: DGMI_LAUNCH(false, false, false); break;
     case 1: DGMI_LAUNCH(false, false, true); break;
@@ -256,15 +358,15 @@ hipError_t launch_vec4(const SpmmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_dword(const SpmmArgs& a, hipStream_t s) {
-  dim3 grid((unsigned)((a.n_dst + kWavesPerBlock - 1) / kWavesPerBlock),
-            (unsigned)((a.F + kWave - 1) / kWave));
+template <bool PLANNED>
+hipError_t launch_dword(const SpmmArgs& a, int64_t segments, hipStream_t s) {
+  dim3 grid(blocks_for(segments), (unsigned)((a.F + kWave - 1) / kWave));
   dim3 block(kWave * kWavesPerBlock);
   const int key = (a.vals ? 4 : 0) | (a.src_scale ? 2 : 0) | (a.dst_scale ? 1 : 0);
-#define DGMI_LAUNCH(V, S, D)                                                         \
-  hipLaunchKernelGGL((spmm_csr_dword_kernel<V, S, D>), grid, block, 0, s, a.indptr,   \
-                     a.indices, a.vals, a.X, a.ldx, a.src_scale, a.dst_scale, a.Y,    \
-                     a.ldy, a.n_dst, (int)a.F)
+#define DGMI_LAUNCH(V, S, D)                                                              \
+  hipLaunchKernelGGL((spmm_csr_dword_kernel<V, S, D, PLANNED>), grid, block, 0, s,         \
+                     a.indptr, a.indices, a.vals, a.X, a.ldx, a.src_scale, a.dst_scale,    \
+                     a.Y, a.ldy, a.n_dst, (int)a.F, a.plan, a.partials, a.ldp)
   switch (key) {
     case 0: DGMI_LAUNCH(false, false, false); break;
     case 1: DGMI_LAUNCH(false, false, true); break;
@@ -277,20 +379,62 @@ hipError_t launch_dword(const SpmmArgs& a, hipStream_t s) {
   }
 #undef DGMI_LAUNCH
   return hipGetLastError();
+}
+
+// Lanes-per-row for a 16-B-aligned width: the widest tile whose last tile is
+// still >= 85 % used (F=344 -> 32 lanes x 3 tiles, not 64 x 2 at 67 %).
+inline int pick_lpr(int64_t F) {
+  const int64_t f4 = (F + 3) / 4;
+  int best = 8;
+  double best_util = 0.0;
+  for (int lpr : {64, 32, 16, 8}) {
+    const int64_t tiles = (f4 + lpr - 1) / lpr;
+    const double util = (double)f4 / (double)(tiles * lpr);
+    if (util >= 0.85) return lpr;
+    if (util > best_util + 1e-9) {
+      best_util = util;
+      best = lpr;
+    }
+  }
+  return best;
+}
+
+template <bool PLANNED>
+hipError_t dispatch(const SpmmArgs& a, int64_t segments, hipStream_t s) {
+  const bool aligned = (a.F % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) &&
+                       ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0) &&
+                       ((reinterpret_cast<uintptr_t>(a.Y) & 15) == 0) &&
+                       (!PLANNED || ((a.ldp % 4 == 0) &&
+                                     ((reinterpret_cast<uintptr_t>(a.partials) & 15) == 0)));
+  if (!aligned) return launch_dword<PLANNED>(a, segments, s);
+  switch (pick_lpr(a.F)) {
+    case 8: return launch_vec4<8, PLANNED>(a, segments, s);
+    case 16: return launch_vec4<16, PLANNED>(a, segments, s);
+    case 32: return launch_vec4<32, PLANNED>(a, segments, s);
+    default: return launch_vec4<64, PLANNED>(a, segments, s);
+  }
 }
 
 }  // namespace
 
 hipError_t spmm_csr_f32(const SpmmArgs& a, hipStream_t s) {
   if (a.n_dst == 0 || a.F == 0) return hipSuccess;
-  const bool aligned = (a.F % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) &&
-                       ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0) &&
-                       ((reinterpret_cast<uintptr_t>(a.Y) & 15) == 0);
-  if (!aligned) return launch_dword(a, s);
-  if (a.F <= 32) return launch_vec4<8>(a, s);
-  if (a.F <= 64) return launch_vec4<16>(a, s);
-  if (a.F <= 128) return launch_vec4<32>(a, s);
-  return launch_vec4<64>(a, s);
+  if (a.plan == nullptr) return dispatch<false>(a, a.n_dst, s);
+
+  const int64_t items_cap = plan_items_cap(a.n_dst, a.nnz, a.chunk);
+  const int64_t long_cap = plan_long_cap(a.nnz, a.chunk);
+  hipError_t err = dispatch<true>(a, items_cap, s);
+  if (err != hipSuccess || long_cap == 0) return err;
+  const unsigned rblocks = blocks_for(long_cap) < 1024u ? blocks_for(long_cap) : 1024u;
+  dim3 grid(rblocks, (unsigned)((a.F + kWave - 1) / kWave));
+  dim3 block(kWave * kWavesPerBlock);
+  if (a.dst_scale)
+    hipLaunchKernelGGL(spmm_reduce_partials_kernel<true>, grid, block, 0, s, a.plan, a.partials,
+                       a.ldp, a.dst_scale, a.Y, a.ldy, (int)a.F, items_cap);
+  else
+    hipLaunchKernelGGL(spmm_reduce_partials_kernel<false>, grid, block, 0, s, a.plan, a.partials,
+                       a.ldp, a.dst_scale, a.Y, a.ldy, (int)a.F, items_cap);
+  return hipGetLastError();
 }
 
 }  // namespace dgmi

@@ -49,6 +49,7 @@ class RelationGraph:
         self.n_src, self.n_dst = int(n_src), int(n_dst)
         self.srcdata, self.dstdata = srcdata, dstdata
         self._csr: Optional[ops.CSRGraph] = None
+        self.trusted = False  # ids already validated (edge lists derived from a checked graph)
 
     # -- the DGL surface the reference's layer code uses ---------------------------------
     def number_of_src_nodes(self) -> int:
@@ -88,7 +89,7 @@ class RelationGraph:
     @property
     def csr(self) -> ops.CSRGraph:
         if self._csr is None:
-            self._csr = ops.CSRGraph(self.dst, self.src, self.n_dst, self.n_src)
+            self._csr = ops.CSRGraph(self.dst, self.src, self.n_dst, self.n_src, check_range=not self.trusted)
         return self._csr
 
 
@@ -295,6 +296,8 @@ def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
         perm = torch.randperm(E, device=rel.device, generator=generator)[:keep]
         data[can] = (rel.src[perm], rel.dst[perm])
     out = HeteroGraph(data, {nt: graph.number_of_nodes(nt) for nt in graph.ntypes})
+    for can in out.canonical_etypes:
+        out[can].trusted = True  # a subset of an existing graph's edges: no range re-check, no host sync
     for nt in graph.ntypes:
         for k, v in graph.nodes[nt].data.items():
             out.nodes[nt].data[k] = v.clone()
@@ -309,4 +312,6 @@ def random_edge_dropout_sparse(adj: torch.Tensor, dropout_rate: float = 0.1,
     E = val.shape[0]
     keep = max(1, int(E * (1 - dropout_rate)))
     perm = torch.randperm(E, device=adj.device, generator=generator)[:keep]
-    return torch.sparse_coo_tensor(idx[:, perm], val[perm], adj.shape, device=adj.device)
+    out = torch.sparse_coo_tensor(idx[:, perm], val[perm], adj.shape, device=adj.device)
+    out._dgmi_trusted = True  # a subset of a valid adjacency: adjacency_csr skips the id re-check (no host sync)
+    return out

@@ -121,11 +121,22 @@ class GCMCGraphConv(nn.Module):
                                 "please set weight=False.")
             if weight is None:
                 weight = self.weight
+            # Keep the gather on the 16-B-per-lane kernel: a message width that is not a multiple
+            # of 4 floats (layer 0 runs at 1024 // 3 = 341, layers.py:55-57) is computed into a
+            # zero-padded buffer (341 -> 344 columns) and sliced back; the values are unchanged.
+            width = None
             if weight is not None:
+                if feat.shape[1] != 3 and weight.shape[1] % 4 != 0:
+                    width = weight.shape[1]
+                    weight = F.pad(weight, (0, -width % 4))
                 feat = dot_or_identity(feat, weight, self.device)
+            if feat.shape[1] % 4 != 0:
+                width = feat.shape[1]
+                feat = F.pad(feat, (0, -width % 4))
 
             cj_drop = self.dropout(cj).view(-1, 1)
-            return ops.spmm_csr(graph.csr, feat, src_scale=cj_drop, dst_scale=ci)
+            rst = ops.spmm_csr(graph.csr, feat, src_scale=cj_drop, dst_scale=ci)
+            return rst if width is None else rst[:, :width]
 
 
 class HeteroGraphConv(nn.Module):
@@ -268,7 +279,8 @@ def adjacency_csr(adj) -> ops.CSRGraph:
     n_dst, n_src = adj.shape
     if max(n_dst, n_src) >= 2 ** 31 - 1:
         raise RuntimeError("adjacency too large for int32 ids")
-    g = ops.CSRGraph(idx[0].to(torch.int32), idx[1].to(torch.int32), n_dst, n_src, vals=val)
+    g = ops.CSRGraph(idx[0].to(torch.int32), idx[1].to(torch.int32), n_dst, n_src, vals=val,
+                     check_range=not getattr(adj, "_dgmi_trusted", False))
     for k in [k for k, v in _ADJ_CACHE.items() if v[0]() is None]:
         del _ADJ_CACHE[k]
     _ADJ_CACHE[key] = (weakref.ref(adj), adj._version, g)

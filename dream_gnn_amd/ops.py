@@ -9,6 +9,8 @@ Boundary being replaced (reference ``/root/reference/layers.py``):
 """
 from __future__ import annotations
 
+import contextlib
+import ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -16,6 +18,7 @@ import torch
 from . import _lib
 
 _L = _lib.lib
+_NULLCTX = contextlib.nullcontext()
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -23,7 +26,15 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _stream(device) -> int:
-    return torch.cuda.current_stream(device).cuda_stream
+    """Raw hipStream_t of torch's current stream on ``device`` (kernels are enqueued there)."""
+    return torch._C._cuda_getCurrentRawStream(device.index)
+
+
+def _guard(device):
+    """Make ``device`` current for the launch; free when it already is (the common case)."""
+    if torch.cuda.current_device() == device.index:
+        return _NULLCTX
+    return torch.cuda.device(device)
 
 
 def _require_device(*tensors):
@@ -51,14 +62,14 @@ def _check(t, dtype, name, ndim=None):
         raise RuntimeError("%s must be contiguous" % name)
 
 
-def csr_from_coo(row: torch.Tensor, col: torch.Tensor, n_rows: int,
+def csr_from_coo(row: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: int = 0,
                  check_range: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Stable COO -> CSR on the device: ``(indptr[n_rows+1], indices[E], eid[E])``, all int32.
 
     ``eid`` is the stable permutation (``argsort(row, kind='stable')``); duplicates are kept.
     Replaces DGL's COO->CSR behind ``dgl.heterograph`` (data_loader.py:448, augmentation.py:65).
-    ``check_range=True`` reads the kernel's error flag back (one host sync) and raises on an
-    out-of-range row id.
+    ``check_range=True`` reads the kernel's error flag back (one host sync) and raises if a row
+    id is outside ``[0, n_rows)`` or, with ``n_cols > 0``, a column id outside ``[0, n_cols)``.
     """
     dev = _require_device(row, col)
     _check(row, torch.int32, "row", 1)
@@ -66,22 +77,21 @@ def csr_from_coo(row: torch.Tensor, col: torch.Tensor, n_rows: int,
     if row.shape != col.shape:
         raise RuntimeError("row/col length mismatch")
     E = row.shape[0]
-    with torch.cuda.device(dev):
+    with _guard(dev):
         indptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
         indices = torch.empty(E, dtype=torch.int32, device=dev)
         eid = torch.empty(E, dtype=torch.int32, device=dev)
-        import ctypes
         need = ctypes.c_size_t(0)
-        _lib.check(_L.dgmi_csr_from_coo_i32(_ptr(row), _ptr(col), E, n_rows, None, None, None, None,
+        _lib.check(_L.dgmi_csr_from_coo_i32(_ptr(row), _ptr(col), E, n_rows, n_cols, None, None, None, None,
                                             ctypes.byref(need), None), "dgmi_csr_from_coo_i32(size query)")
         ws = torch.empty(max(int(need.value), 256), dtype=torch.uint8, device=dev)
         have = ctypes.c_size_t(ws.numel())
-        _lib.check(_L.dgmi_csr_from_coo_i32(_ptr(row), _ptr(col), E, n_rows, _ptr(indptr), _ptr(indices),
+        _lib.check(_L.dgmi_csr_from_coo_i32(_ptr(row), _ptr(col), E, n_rows, n_cols, _ptr(indptr), _ptr(indices),
                                             _ptr(eid), _ptr(ws), ctypes.byref(have), _stream(dev)),
                    "dgmi_csr_from_coo_i32")
-        if check_range:
-            if int(ws[:4].view(torch.int32).item()) != 0:
-                raise RuntimeError("csr_from_coo: a row id is outside [0, %d)" % n_rows)
+        if check_range and int(ws[:4].view(torch.int32).item()) != 0:
+            raise RuntimeError("csr_from_coo: an id is outside [0, %d) x [0, %s)"
+                               % (n_rows, n_cols if n_cols > 0 else "unchecked"))
     return indptr, indices, eid
 
 
@@ -90,49 +100,119 @@ def gather_f32(values: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
     _check(values, torch.float32, "values", 1)
     _check(perm, torch.int32, "perm", 1)
     out = torch.empty(perm.shape[0], dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _lib.check(_L.dgmi_gather_f32(_ptr(values), _ptr(perm), perm.shape[0], _ptr(out), _stream(dev)),
                    "dgmi_gather_f32")
     return out
 
 
-def spmm_csr_raw(indptr, indices, vals, X, src_scale=None, dst_scale=None, out=None) -> torch.Tensor:
-    """One ``dgmi_spmm_csr_f32`` call, no autograd.  X may be a row-strided 2-D view."""
-    dev = _require_device(indptr, indices, vals, X, src_scale, dst_scale, out)
-    _check(indptr, torch.int32, "indptr", 1)
-    _check(indices, torch.int32, "indices", 1)
+class SpmmPlan:
+    """nnz-balanced launch plan of one CSR (``dgmi_spmm_plan_build``): rows longer than
+    ``chunk`` edges are cut into one-wave chunks.  Depends only on ``indptr``."""
+
+    def __init__(self, indptr: torch.Tensor, nnz: int, chunk: Optional[int] = None):
+        dev = _require_device(indptr)
+        self.n_rows = int(indptr.shape[0] - 1)
+        self.nnz = int(nnz)
+        self.chunk = int(chunk) if chunk else int(_L.dgmi_spmm_default_chunk(self.n_rows, self.nnz))
+        nbytes = int(_L.dgmi_spmm_plan_bytes(self.n_rows, self.nnz, self.chunk))
+        if nbytes == 0:
+            raise RuntimeError("invalid plan parameters (chunk=%d)" % self.chunk)
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._pbytes = {}
+        with _guard(dev):
+            need = ctypes.c_size_t(0)
+            _lib.check(_L.dgmi_spmm_plan_build(_ptr(indptr), self.n_rows, self.nnz, self.chunk, None, 0, None,
+                                               ctypes.byref(need), None), "dgmi_spmm_plan_build(size query)")
+            ws = torch.empty(max(int(need.value), 256), dtype=torch.uint8, device=dev)
+            have = ctypes.c_size_t(ws.numel())
+            _lib.check(_L.dgmi_spmm_plan_build(_ptr(indptr), self.n_rows, self.nnz, self.chunk, _ptr(self.buf),
+                                               nbytes, _ptr(ws), ctypes.byref(have), _stream(dev)),
+                       "dgmi_spmm_plan_build")
+
+    def partials_bytes(self, F: int) -> int:
+        b = self._pbytes.get(F)
+        if b is None:
+            b = self._pbytes[F] = int(_L.dgmi_spmm_partials_bytes(self.nnz, self.chunk, int(F)))
+        return b
+
+    def header(self):
+        """(n_items, n_long_rows, n_slots, chunk, ...) — reads the device header back (tests)."""
+        return tuple(int(v) for v in self.buf[:64].view(torch.int32).tolist())
+
+
+def build_plan(indptr: torch.Tensor, nnz: int, chunk: Optional[int] = None) -> SpmmPlan:
+    return SpmmPlan(indptr, nnz, chunk)
+
+
+def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx):
+    """Validated arguments -> one C-ABI call on torch's current stream."""
+    with _guard(dev):
+        if plan is None:
+            rc = _L.dgmi_spmm_csr_f32(indptr.data_ptr(), indices.data_ptr(), _ptr(vals), X.data_ptr(), ldx,
+                                      _ptr(src_scale), _ptr(dst_scale), out.data_ptr(), max(F, 1), n_dst, n_src, F,
+                                      _stream(dev))
+            if rc:
+                _lib.check(rc, "dgmi_spmm_csr_f32")
+        else:
+            pbytes = plan.partials_bytes(F)
+            partials = torch.empty(pbytes, dtype=torch.uint8, device=dev)  # caching allocator: stream-safe scratch
+            rc = _L.dgmi_spmm_csr_planned_f32(indptr.data_ptr(), indices.data_ptr(), _ptr(vals), X.data_ptr(), ldx,
+                                              _ptr(src_scale), _ptr(dst_scale), out.data_ptr(), max(F, 1), n_dst,
+                                              n_src, F, plan.nnz, plan.chunk, plan.buf.data_ptr(),
+                                              partials.data_ptr(), pbytes, _stream(dev))
+            if rc:
+                _lib.check(rc, "dgmi_spmm_csr_planned_f32")
+    return out
+
+
+def _prep_dense(X):
     if X.dtype != torch.float32 or X.dim() != 2:
         raise RuntimeError("X must be a 2-D float32 tensor, got %s %s" % (X.dtype, tuple(X.shape)))
     if X.stride(1) != 1 or (X.shape[0] > 1 and X.stride(0) < X.shape[1]):
         X = X.contiguous()
     n_src, F = X.shape
-    ldx = X.stride(0) if n_src > 1 else max(F, 1)
+    return X, n_src, F, (X.stride(0) if n_src > 1 else max(F, 1))
+
+
+def _prep_scale(s, n, name):
+    if s is None:
+        return None
+    if s.dim() != 1:
+        s = s.reshape(-1)
+    if s.dtype != torch.float32 or s.shape[0] != n or not s.is_contiguous():
+        if s.dtype != torch.float32:
+            raise RuntimeError("%s must be float32" % name)
+        if s.shape[0] != n:
+            raise RuntimeError("%s has %d entries, expected %d" % (name, s.shape[0], n))
+        s = s.contiguous()
+    return s
+
+
+def spmm_csr_raw(indptr, indices, vals, X, src_scale=None, dst_scale=None, out=None,
+                 plan: Optional[SpmmPlan] = None) -> torch.Tensor:
+    """One SpMM launch through the C ABI, no autograd.  X may be a row-strided 2-D view.
+    ``plan=None``: ``dgmi_spmm_csr_f32`` (a wave per row); else ``dgmi_spmm_csr_planned_f32``."""
+    dev = _require_device(indptr, indices, vals, X, src_scale, dst_scale, out)
+    _check(indptr, torch.int32, "indptr", 1)
+    _check(indices, torch.int32, "indices", 1)
+    X, n_src, F, ldx = _prep_dense(X)
     n_dst = indptr.shape[0] - 1
     if vals is not None:
         _check(vals, torch.float32, "vals", 1)
         if vals.shape[0] != indices.shape[0]:
             raise RuntimeError("vals/indices length mismatch")
-    if src_scale is not None:
-        src_scale = src_scale.reshape(-1)
-        _check(src_scale, torch.float32, "src_scale", 1)
-        if src_scale.shape[0] != n_src:
-            raise RuntimeError("src_scale has %d entries, X has %d rows" % (src_scale.shape[0], n_src))
-    if dst_scale is not None:
-        dst_scale = dst_scale.reshape(-1)
-        _check(dst_scale, torch.float32, "dst_scale", 1)
-        if dst_scale.shape[0] != n_dst:
-            raise RuntimeError("dst_scale has %d entries, graph has %d rows" % (dst_scale.shape[0], n_dst))
+    src_scale = _prep_scale(src_scale, n_src, "src_scale")
+    dst_scale = _prep_scale(dst_scale, n_dst, "dst_scale")
     if out is None:
         out = torch.empty((n_dst, F), dtype=torch.float32, device=dev)
     else:
         _check(out, torch.float32, "out", 2)
         if tuple(out.shape) != (n_dst, F):
             raise RuntimeError("out has shape %s, expected %s" % (tuple(out.shape), (n_dst, F)))
-    with torch.cuda.device(dev):
-        _lib.check(_L.dgmi_spmm_csr_f32(_ptr(indptr), _ptr(indices), _ptr(vals), _ptr(X), ldx, _ptr(src_scale),
-                                        _ptr(dst_scale), _ptr(out), max(F, 1), n_dst, n_src, F, _stream(dev)),
-                   "dgmi_spmm_csr_f32")
-    return out
+    if plan is not None and (plan.n_rows != n_dst or plan.nnz != indices.shape[0]):
+        raise RuntimeError("plan was built for another CSR")
+    return _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx)
 
 
 class CSRGraph:
@@ -140,24 +220,26 @@ class CSRGraph:
 
     Holds the destination-major CSR (forward: ``Y = A X``) and, built lazily on first
     backward, the source-major CSR of the reversed edges (``dX = A^T dY``), both made by the
-    device COO->CSR.  ``vals`` (optional) are per-edge values in the caller's COO order.
-    Row = destination, col = source, as in ``th.spmm(adj, x)`` where ``adj[dst, src]``.
+    device COO->CSR, each with its launch plan.  ``vals`` (optional) are per-edge values in
+    the caller's COO order.  Row = destination, col = source, as in ``th.spmm(adj, x)`` where
+    ``adj[dst, src]``.  ``check_range=True`` costs one host sync (error-flag readback); pass
+    ``False`` for edge lists derived from an already validated graph (edge dropout).
     """
 
     def __init__(self, dst: torch.Tensor, src: torch.Tensor, n_dst: int, n_src: int,
-                 vals: Optional[torch.Tensor] = None, check_range: bool = True):
+                 vals: Optional[torch.Tensor] = None, check_range: bool = True, planned: bool = True):
         _require_device(dst, src, vals)
         self.n_dst, self.n_src = int(n_dst), int(n_src)
         self._dst = dst.to(torch.int32).contiguous()
         self._src = src.to(torch.int32).contiguous()
         self._coo_vals = None if vals is None else vals.to(torch.float32).contiguous()
-        if check_range and self._src.numel():
-            lo, hi = int(self._src.min()), int(self._src.max())
-            if lo < 0 or hi >= self.n_src:
-                raise RuntimeError("source id out of range [0, %d): min %d max %d" % (self.n_src, lo, hi))
-        self.indptr, self.indices, self.eid = csr_from_coo(self._dst, self._src, self.n_dst,
+        if self._coo_vals is not None and self._coo_vals.shape[0] != self._dst.shape[0]:
+            raise RuntimeError("vals/edge-list length mismatch")
+        self.indptr, self.indices, self.eid = csr_from_coo(self._dst, self._src, self.n_dst, self.n_src,
                                                            check_range=check_range)
         self.vals = None if self._coo_vals is None else gather_f32(self._coo_vals, self.eid)
+        self._planned = planned
+        self.plan = build_plan(self.indptr, self.nnz) if planned else None
         self._t = None
 
     @property
@@ -169,12 +251,38 @@ class CSRGraph:
         return self.indptr.device
 
     def transposed(self):
-        """(indptr_t, indices_t, vals_t): CSR of the reversed edges, rows = source nodes."""
+        """(indptr_t, indices_t, vals_t, plan_t): CSR of the reversed edges, rows = source nodes."""
         if self._t is None:
             indptr_t, indices_t, eid_t = csr_from_coo(self._src, self._dst, self.n_src)
             vals_t = None if self._coo_vals is None else gather_f32(self._coo_vals, eid_t)
-            self._t = (indptr_t, indices_t, vals_t)
+            plan_t = build_plan(indptr_t, self.nnz) if self._planned else None
+            self._t = (indptr_t, indices_t, vals_t, plan_t)
         return self._t
+
+    def _run(self, indptr, indices, vals, plan, n_rows, n_cols, X, col_scale, row_scale, out):
+        dev = indptr.device
+        if not X.is_cuda or X.device != dev:
+            _require_device(indptr, X)
+        X, n_x, F, ldx = _prep_dense(X)
+        if n_x != n_cols:
+            raise RuntimeError("X has %d rows, the graph has %d source nodes" % (n_x, n_cols))
+        col_scale = _prep_scale(col_scale, n_cols, "src_scale")
+        row_scale = _prep_scale(row_scale, n_rows, "dst_scale")
+        if out is None:
+            out = torch.empty((n_rows, F), dtype=torch.float32, device=dev)
+        elif out.dtype != torch.float32 or tuple(out.shape) != (n_rows, F) or not out.is_contiguous():
+            raise RuntimeError("out must be a contiguous float32 (%d, %d) tensor" % (n_rows, F))
+        return _launch_spmm(dev, indptr, indices, vals, X, col_scale, row_scale, out, plan, n_rows, n_cols, F, ldx)
+
+    def spmm(self, X, src_scale=None, dst_scale=None, out=None):
+        """``diag(dst_scale) A diag(src_scale) X`` (no autograd)."""
+        return self._run(self.indptr, self.indices, self.vals, self.plan, self.n_dst, self.n_src, X,
+                         src_scale, dst_scale, out)
+
+    def spmm_t(self, dY, src_scale=None, dst_scale=None, out=None):
+        """``diag(src_scale) A^T diag(dst_scale) dY`` — the backward of :meth:`spmm`."""
+        indptr_t, indices_t, vals_t, plan_t = self.transposed()
+        return self._run(indptr_t, indices_t, vals_t, plan_t, self.n_src, self.n_dst, dY, dst_scale, src_scale, out)
 
 
 class _SpMM(torch.autograd.Function):
@@ -182,18 +290,16 @@ class _SpMM(torch.autograd.Function):
     def forward(ctx, X, g: CSRGraph, src_scale, dst_scale):
         ctx.g = g
         ctx.save_for_backward(src_scale, dst_scale)
-        return spmm_csr_raw(g.indptr, g.indices, g.vals, X, src_scale, dst_scale)
+        return g.spmm(X, src_scale, dst_scale)
 
     @staticmethod
     def backward(ctx, dY):
         src_scale, dst_scale = ctx.saved_tensors
-        g = ctx.g
         dX = None
         if ctx.needs_input_grad[0]:
-            indptr_t, indices_t, vals_t = g.transposed()
             # dX = diag(src_scale) A^T diag(dst_scale) dY : the same kernel on the reversed
             # edges with the two scales swapped.
-            dX = spmm_csr_raw(indptr_t, indices_t, vals_t, dY.contiguous(), dst_scale, src_scale)
+            dX = ctx.g.spmm_t(dY, src_scale, dst_scale)
         return dX, None, None, None
 
 

@@ -61,7 +61,7 @@ class RowShard:
     def spmm_local(self, X, src_scale=None, dst_scale=None, out=None):
         """Rows [lo, hi) of ``diag(dst_scale) A diag(src_scale) X``; scales are full-length."""
         ds = None if dst_scale is None else dst_scale.reshape(-1)[self.lo:self.hi].contiguous()
-        return ops.spmm_csr_raw(self.local.indptr, self.local.indices, self.local.vals, X, src_scale, ds, out=out)
+        return self.local.spmm(X, src_scale, ds, out=out)
 
     def gather_rows(self, y_local: torch.Tensor, group=None, out: Optional[torch.Tensor] = None,
                     async_op: bool = False):
@@ -128,7 +128,7 @@ class EdgeShard:
 
     def spmm(self, X, src_scale=None, dst_scale=None):
         # dst_scale is linear: apply it after the reduce (once), src_scale inside the kernel
-        y = ops.spmm_csr_raw(self.local.indptr, self.local.indices, self.local.vals, X, src_scale, None)
+        y = self.local.spmm(X, src_scale, None)
         dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
         if dst_scale is not None:
             y = y * dst_scale.reshape(-1, 1)

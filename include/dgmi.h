@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 1
+#define DGMI_ABI_VERSION 3
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -81,12 +81,13 @@ DGMI_API int dgmi_device_ok(void);
  * Workspace protocol: call with workspace == NULL to get the required size in
  * *workspace_bytes (nothing is launched); then call again with a device
  * buffer of at least that size.  The first int32 of the workspace is an error
- * flag the launch sets to 1 if any row id is outside [0, n_rows): read it back
- * after synchronising the stream if the ids are untrusted.
+ * flag the launch sets to 1 if any row id is outside [0, n_rows) or — when n_cols > 0 —
+ * any column id is outside [0, n_cols): read it back after synchronising the stream if the
+ * ids are untrusted (n_cols <= 0 skips the column check).
  * E == 0 is valid (indptr is zero-filled).
  */
 DGMI_API int dgmi_csr_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
-                          int64_t n_rows, int32_t* indptr, int32_t* indices,
+                          int64_t n_rows, int64_t n_cols, int32_t* indptr, int32_t* indices,
                           int32_t* eid, void* workspace, size_t* workspace_bytes,
                           dgmi_stream_t stream);
 
@@ -114,6 +115,40 @@ DGMI_API int dgmi_spmm_csr_f32(const int32_t* indptr, const int32_t* indices,
                       const float* src_scale, const float* dst_scale, float* Y,
                       int64_t ldy, int64_t n_dst, int64_t n_src, int64_t F,
                       dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
+ * Planned SpMM: the same product with an nnz-balanced launch.
+ *
+ * dgmi_spmm_csr_f32 gives one wave to each destination row, which is right for regular
+ * degrees (kNN graphs, the uniform synthetic bipartite graph) and wrong for power-law degree
+ * distributions (one 10^6-edge row = one wave) or for the reference's near-complete
+ * bipartite slices (~700 rows of ~680 edges: too few waves for 256 CUs).  A *plan* cuts rows
+ * into chunks of at most `chunk` edges, one wave each; partial sums of multi-chunk rows go to
+ * a caller-provided `partials` buffer and are added in chunk order by a second kernel, so the
+ * result stays bitwise reproducible.  The plan depends only on indptr and `chunk`; build it
+ * once per CSR (it is rebuilt with the CSR after edge dropout) and reuse it for every F.
+ *
+ *   chunk    = dgmi_spmm_default_chunk(n_rows, nnz)          (or any value in [16, 65536])
+ *   plan     = device buffer of dgmi_spmm_plan_bytes(n_rows, nnz, chunk) bytes
+ *   dgmi_spmm_plan_build(...)                                 workspace protocol as above
+ *   partials = device buffer of dgmi_spmm_partials_bytes(nnz, chunk, F) bytes (16-B aligned);
+ *              scratch, may be shared by calls that are ordered on one stream
+ *   dgmi_spmm_csr_planned_f32(...)                            same semantics as dgmi_spmm_csr_f32
+ * Sizes are upper bounds computed from (n_rows, nnz, chunk) alone; nothing is read back.
+ */
+DGMI_API int32_t dgmi_spmm_default_chunk(int64_t n_rows, int64_t nnz);
+DGMI_API size_t dgmi_spmm_plan_bytes(int64_t n_rows, int64_t nnz, int32_t chunk);
+DGMI_API size_t dgmi_spmm_partials_bytes(int64_t nnz, int32_t chunk, int64_t F);
+DGMI_API int dgmi_spmm_plan_build(const int32_t* indptr, int64_t n_rows, int64_t nnz,
+                                  int32_t chunk, void* plan, size_t plan_bytes, void* workspace,
+                                  size_t* workspace_bytes, dgmi_stream_t stream);
+DGMI_API int dgmi_spmm_csr_planned_f32(const int32_t* indptr, const int32_t* indices,
+                                       const float* vals, const float* X, int64_t ldx,
+                                       const float* src_scale, const float* dst_scale, float* Y,
+                                       int64_t ldy, int64_t n_dst, int64_t n_src, int64_t F,
+                                       int64_t nnz, int32_t chunk, const void* plan,
+                                       void* partials, size_t partials_bytes,
+                                       dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
  * Gather of per-edge values through a permutation: out[p] = in[perm[p]].

@@ -13,7 +13,7 @@ import torch
 from oracle import oracle as O
 
 
-def csr_from_coo(row, col, n_rows, check_range=False):
+def csr_from_coo(row, col, n_rows, n_cols=0, check_range=False):
     indptr, indices, eid = O.csr_from_coo(row.cpu().numpy(), col.cpu().numpy(), int(n_rows))
     return torch.from_numpy(indptr), torch.from_numpy(indices), torch.from_numpy(eid)
 
@@ -22,7 +22,7 @@ def gather_f32(values, perm):
     return values[perm.long()].contiguous()
 
 
-def spmm_csr_raw(indptr, indices, vals, X, src_scale=None, dst_scale=None, out=None):
+def spmm_csr_raw(indptr, indices, vals, X, src_scale=None, dst_scale=None, out=None, plan=None):
     n = lambda t: None if t is None else t.detach().cpu().numpy()
     y = O.spmm_csr(n(indptr), n(indices), n(vals), np.ascontiguousarray(n(X)), n(src_scale), n(dst_scale))
     y = torch.from_numpy(y)
@@ -32,13 +32,20 @@ def spmm_csr_raw(indptr, indices, vals, X, src_scale=None, dst_scale=None, out=N
     return y
 
 
+def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx):
+    return spmm_csr_raw(indptr, indices, vals, X, src_scale, dst_scale, out=out)
+
+
 @contextlib.contextmanager
 def patched():
     from dream_gnn_amd import ops
 
-    saved = {k: getattr(ops, k) for k in ("csr_from_coo", "gather_f32", "spmm_csr_raw", "_require_device")}
+    names = ("csr_from_coo", "gather_f32", "spmm_csr_raw", "_launch_spmm", "_require_device", "build_plan")
+    saved = {k: getattr(ops, k) for k in names}
     ops.csr_from_coo, ops.gather_f32, ops.spmm_csr_raw = csr_from_coo, gather_f32, spmm_csr_raw
+    ops._launch_spmm = _launch_spmm
     ops._require_device = lambda *ts: next((t.device for t in ts if t is not None), None)
+    ops.build_plan = lambda indptr, nnz, chunk=None: None  # launch plans are a device-side concern
     try:
         yield
     finally:

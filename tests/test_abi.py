@@ -17,7 +17,9 @@ def _declared():
 
 def test_header_declares_the_expected_entry_points():
     assert _declared() == ["dgmi_abi_version", "dgmi_csr_from_coo_i32", "dgmi_device_ok", "dgmi_gather_f32",
-                           "dgmi_spmm_csr_f32", "dgmi_status_string"]
+                           "dgmi_spmm_csr_f32", "dgmi_spmm_csr_planned_f32", "dgmi_spmm_default_chunk",
+                           "dgmi_spmm_partials_bytes", "dgmi_spmm_plan_build", "dgmi_spmm_plan_bytes",
+                           "dgmi_status_string"]
 
 
 def test_library_exports_every_declared_symbol():
@@ -45,14 +47,26 @@ def test_argument_validation_returns_codes_without_a_gpu():
 
     L = _lib.lib
     need = ctypes.c_size_t(0)
-    assert L.dgmi_csr_from_coo_i32(None, None, -1, 4, None, None, None, None, ctypes.byref(need), None) == -1
-    assert L.dgmi_csr_from_coo_i32(None, None, 1, 4, None, None, None, None, None, None) == -1
-    assert L.dgmi_csr_from_coo_i32(None, None, 2 ** 31, 4, None, None, None, None, ctypes.byref(need), None) == -2
+    assert L.dgmi_csr_from_coo_i32(None, None, -1, 4, 0, None, None, None, None, ctypes.byref(need), None) == -1
+    assert L.dgmi_csr_from_coo_i32(None, None, 1, 4, 0, None, None, None, None, None, None) == -1
+    assert L.dgmi_csr_from_coo_i32(None, None, 2 ** 31, 4, 0, None, None, None, None, ctypes.byref(need), None) == -2
     assert L.dgmi_spmm_csr_f32(None, None, None, None, 4, None, None, None, 4, -1, 1, 4, None) == -1
     assert L.dgmi_spmm_csr_f32(None, None, None, None, 4, None, None, None, 4, 2, 2, 4, None) == -1  # null indptr/Y
     assert L.dgmi_spmm_csr_f32(None, None, None, None, 4, None, None, None, 4, 0, 0, 4, None) == 0   # empty problem
     assert L.dgmi_spmm_csr_f32(16, 16, None, 16, 2, None, None, 32, 4, 2, 2, 4, None) == -1          # ldx < F
     assert L.dgmi_spmm_csr_f32(16, 16, None, 64, 4, None, None, 64, 4, 2, 2, 4, None) == -1          # Y aliases X
+    # plan sizing is host arithmetic: items <= n_rows + nnz/chunk, long rows <= nnz/(chunk+1)
+    assert L.dgmi_spmm_default_chunk(50_000, 10_000_000) == 512
+    assert L.dgmi_spmm_default_chunk(681, 465_000) == 128
+    assert L.dgmi_spmm_default_chunk(763, 6_800) == 64
+    assert L.dgmi_spmm_plan_bytes(10, 100, 64) == 4 * (16 + 4 * (10 + 1 + 1))
+    assert L.dgmi_spmm_plan_bytes(10, 100, 3) == 0  # chunk out of range
+    assert L.dgmi_spmm_partials_bytes(1000, 64, 128) == (15 + 15) * 128 * 4
+    assert L.dgmi_spmm_partials_bytes(1000, 64, 341) == (15 + 15) * 344 * 4
+    assert L.dgmi_spmm_partials_bytes(0, 64, 128) == 16
+    assert L.dgmi_spmm_plan_build(None, -1, 0, 64, None, 0, None, ctypes.byref(need), None) == -1
+    assert L.dgmi_spmm_csr_planned_f32(16, 16, None, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 7, 16, 16, 1 << 20, None) == -1
+    assert L.dgmi_spmm_csr_planned_f32(16, 16, None, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 64, 16, 16, 0, None) == -3
     assert L.dgmi_gather_f32(None, None, -3, None, None) == -1
     assert L.dgmi_gather_f32(None, None, 0, None, None) == 0
 

@@ -42,6 +42,12 @@ def _check_close(y_hip, y32, y64, yabs):
     assert float(np.abs(y_hip - y32).max()) <= float(np.abs(y32 - y64).max()) + RTOL * scale
 
 
+def _plans(ops, g):
+    """launch forms to cover: a wave per row, the default plan, and a plan with 16-edge chunks
+    (forces multi-chunk rows + the reduce pass on small graphs)."""
+    return [None, g.plan, ops.build_plan(g.indptr, g.nnz, chunk=16)]
+
+
 @pytest.mark.parametrize("F", [1, 3, 4, 8, 32, 64, 100, 127, 128, 256, 341, 344, 768])
 @pytest.mark.parametrize("mode", ["copy_u", "copy_u_scaled", "u_mul_e", "all"])
 def test_spmm_vs_oracle(oracle, dev, F, mode):
@@ -67,12 +73,12 @@ def test_spmm_vs_oracle(oracle, dev, F, mode):
     assert np.array_equal(g.indptr.cpu().numpy(), indptr)
     assert np.array_equal(g.indices.cpu().numpy(), indices)
     assert np.array_equal(g.eid.cpu().numpy(), eid)
-    y = ops.spmm_csr_raw(g.indptr, g.indices, g.vals, t(X), t(ss), t(ds))
-    torch.cuda.synchronize()
-    _check_close(y.cpu().numpy(), y32, y64, yabs)
-    # empty rows are exactly zero
     deg = np.diff(indptr)
-    assert np.all(y.cpu().numpy()[deg == 0] == 0)
+    for plan in _plans(ops, g):
+        y = ops.spmm_csr_raw(g.indptr, g.indices, g.vals, t(X), t(ss), t(ds), plan=plan)
+        torch.cuda.synchronize()
+        _check_close(y.cpu().numpy(), y32, y64, yabs)
+        assert np.all(y.cpu().numpy()[deg == 0] == 0)  # empty rows are exactly zero
 
 
 @pytest.mark.parametrize("case", ["E0", "one_row", "one_edge", "long_row", "skew", "dups"])
@@ -109,9 +115,15 @@ def test_spmm_edge_cases(oracle, dev, case):
     assert np.array_equal(g.indptr.cpu().numpy(), indptr)
     assert np.array_equal(g.indices.cpu().numpy(), indices)
     assert np.array_equal(g.eid.cpu().numpy(), eid)
-    y = ops.spmm_csr_raw(g.indptr, g.indices, None, torch.from_numpy(X).to(dev))
-    torch.cuda.synchronize()
-    _check_close(y.cpu().numpy(), y32, y64, yabs)
+    for plan in _plans(ops, g):
+        y = ops.spmm_csr_raw(g.indptr, g.indices, None, torch.from_numpy(X).to(dev), plan=plan)
+        torch.cuda.synchronize()
+        _check_close(y.cpu().numpy(), y32, y64, yabs)
+    # the plan itself: every edge in exactly one item, chunks <= chunk, long rows listed once
+    n_items, n_long, n_slots, chunk = g.plan.header()[:4]
+    want_items = int(np.maximum(1, -(-deg // chunk)).sum()) if (deg := np.diff(indptr)).size else 0
+    assert n_items == want_items and n_long == int((deg > chunk).sum())
+    assert n_slots == int((-(-deg // chunk))[deg > chunk].sum())
 
 
 def test_strided_input_and_determinism(oracle, dev):
@@ -127,6 +139,10 @@ def test_strided_input_and_determinism(oracle, dev):
     y2 = ops.spmm_csr_raw(g.indptr, g.indices, None, xb[:, F:].contiguous())
     y3 = ops.spmm_csr_raw(g.indptr, g.indices, None, xb[:, F:])
     assert torch.equal(y1, y2) and torch.equal(y1, y3)  # bitwise reproducible
+    p16 = ops.build_plan(g.indptr, g.nnz, chunk=16)
+    z1 = ops.spmm_csr_raw(g.indptr, g.indices, None, xb[:, F:], plan=p16)
+    z2 = ops.spmm_csr_raw(g.indptr, g.indices, None, xb[:, F:], plan=p16)
+    assert torch.equal(z1, z2)  # chunk partials are added in chunk order: reproducible too
     indptr, indices, _ = oracle.csr_from_coo(dst, src, n_dst)
     y32 = oracle.spmm_csr(indptr, indices, None, np.ascontiguousarray(Xbig[:, F:]))
     assert np.abs(y1.cpu().numpy() - y32).max() <= RTOL * np.abs(y32).max()
@@ -163,3 +179,10 @@ def test_out_of_range_row_is_reported(dev):
     col = torch.tensor([0, 0, 0], dtype=torch.int32, device=dev)
     with pytest.raises(RuntimeError):
         ops.csr_from_coo(row, col, 3, check_range=True)
+    ok_row = torch.tensor([0, 2, 1], dtype=torch.int32, device=dev)
+    bad_col = torch.tensor([0, 7, 0], dtype=torch.int32, device=dev)
+    ops.csr_from_coo(ok_row, bad_col, 3, check_range=True)  # columns unchecked without n_cols
+    with pytest.raises(RuntimeError):
+        ops.csr_from_coo(ok_row, bad_col, 3, n_cols=4, check_range=True)
+    with pytest.raises(RuntimeError):
+        ops.CSRGraph(ok_row, bad_col, 3, 4)

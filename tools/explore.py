@@ -1,0 +1,80 @@
+"""Scratch experiments on the GPU box (not judged): HBM-bound gather (cfg-5 shard shape),
+degree skew, lrssl-shaped small graphs, other feature widths."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from dream_gnn_amd import ops, synth
+
+dev = torch.device("cuda:0")
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts)//2]
+
+def report(name, g, X, F, weighted=False, ss=None, ds=None):
+    Y = torch.empty(g.n_dst, F, device=dev)
+    ms0 = timeit(lambda: ops.spmm_csr_raw(g.indptr, g.indices, g.vals, X, ss, ds, out=Y))
+    ms = timeit(lambda: g.spmm(X, ss, ds, out=Y))
+    name = name + " [unplanned %.1f us, chunk %d]" % (ms0 * 1e3, g.plan.chunk)
+    nnz = g.nnz
+    b = nnz*(4*F+4+(4 if weighted else 0)) + g.n_dst*4*F
+    print(f"{name}: nnz {nnz/1e6:.2f}M rows {g.n_dst} F {F}: {ms*1e3:.1f} us  {nnz/ms/1e6:.2f} Gedge/s  {b/ms/1e6:.0f} GB/s alg", flush=True)
+
+which = sys.argv[1:] or ["hbm", "skew", "small", "widths"]
+gen = torch.Generator(device=dev).manual_seed(0)
+if "hbm" in which:
+    for n_src in (100_000, 400_000, 800_000, 1_600_000):
+        n_dst, E = 50_000, 10_000_000
+        dst = torch.randint(0, n_dst, (E,), generator=gen, device=dev, dtype=torch.int32)
+        src = torch.randint(0, n_src, (E,), generator=gen, device=dev, dtype=torch.int32)
+        g = ops.CSRGraph(dst, src, n_dst, n_src)
+        X = torch.randn(n_src, 128, device=dev)
+        report(f"gather table {n_src*512/1e6:.0f} MB", g, X, 128)
+        del g, X, dst, src
+if "skew" in which:
+    n_dst, n_src, E = 50_000, 100_000, 10_000_000
+    for alpha in (0.0, 0.8, 1.2):
+        p = 1.0 / torch.arange(1, n_dst + 1, device=dev, dtype=torch.float64) ** alpha
+        dst = torch.multinomial(p / p.sum(), E, replacement=True, generator=gen).to(torch.int32)
+        dst = dst[torch.randperm(E, device=dev, generator=gen)]
+        src = torch.randint(0, n_src, (E,), generator=gen, device=dev, dtype=torch.int32)
+        g = ops.CSRGraph(dst, src, n_dst, n_src)
+        deg = (g.indptr[1:] - g.indptr[:-1])
+        X = torch.randn(n_src, 128, device=dev)
+        report(f"zipf alpha {alpha} (max deg {int(deg.max())}, median {int(deg.median())})", g, X, 128)
+        del g, X
+if "small" in which:
+    nd, ns = 763, 681
+    pairs = torch.cartesian_prod(torch.arange(nd), torch.arange(ns)).to(dev)
+    keep = torch.rand(pairs.shape[0], device=dev, generator=gen) < 0.9
+    pairs = pairs[keep]
+    lab = torch.rand(pairs.shape[0], device=dev, generator=gen) < 0.006
+    for nm, sel in (("rel0", ~lab), ("rel1", lab)):
+        d, s = pairs[sel, 0].int(), pairs[sel, 1].int()
+        g = ops.CSRGraph(s, d, ns, nd)
+        for F in (341, 344, 128, 256):
+            X = torch.randn(nd, F, device=dev)
+            report(f"lrssl-shape {nm} drug->disease", g, X, F)
+    r, c, v = synth.knn_sim_graph(nd, 4, 1, dev)
+    g = ops.CSRGraph(r, c, nd, nd, vals=v)
+    for F in (768, 128):
+        report("lrssl-shape knn-4", g, torch.randn(nd, F, device=dev), F, weighted=True)
+    # launch overhead floor: empty graph
+    g0 = ops.CSRGraph(torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev), 4, 4)
+    report("empty (launch floor)", g0, torch.randn(4, 128, device=dev), 128)
+if "widths" in which:
+    n_dst, n_src, E = 50_000, 100_000, 10_000_000
+    dst = torch.randint(0, n_dst, (E,), generator=gen, device=dev, dtype=torch.int32)
+    src = torch.randint(0, n_src, (E,), generator=gen, device=dev, dtype=torch.int32)
+    g = ops.CSRGraph(dst, src, n_dst, n_src)
+    for F in (32, 64, 128, 256, 341, 344, 512, 768):
+        X = torch.randn(n_src, F, device=dev)
+        report("uniform 10M", g, X, F)
+        del X

@@ -55,7 +55,7 @@ with open(os.path.join(out, tag + "_pmc_summary.csv"), "w", newline="") as fh:
     wr.writeheader()
     wr.writerows(rows)
 
-dom = [r for r in rows if "<32, false, true, true>" in r["kernel"]]
+dom = [r for r in rows if "spmm_csr_vec4_kernel<32, false, true, true" in r["kernel"]]
 if dom:
     json.dump({"kernel": dom[0]["kernel"], "hbm_bytes_per_launch": dom[0]["hbm_bytes_corrected_avg"],
                "source": "profiles/%s_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
