@@ -189,11 +189,20 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # One rank per GPU.  (Rehearsal of the N>1 path on a 1-GPU box: DGMI_DIST_BACKEND=gloo lets
+    # several ranks share cuda:0 and stages the all-gather through the host.)
+    backend = os.environ.get("DGMI_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit("rank %d has no GPU (%d visible)" % (local_rank, n_dev))
+    dev = torch.device("cuda", local_rank % n_dev)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import dream_gnn_amd  # noqa: F401  (fails loudly if libdgmi.so is missing)
 

@@ -27,6 +27,17 @@ import torch.distributed as dist
 from . import ops
 
 
+def _all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None):
+    """all_gather_into_tensor; with the gloo backend (CPU rehearsals of the N>1 path, possibly
+    with device tensors) the payload is staged through host memory."""
+    if dist.get_backend(group) == "gloo" and inp.is_cuda:
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host_out, inp.cpu(), group=group)
+        out.copy_(host_out)
+        return
+    dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def balanced_row_bounds(degree: torch.Tensor, parts: int) -> torch.Tensor:
     """Contiguous row ranges with ~equal nnz: int64[parts+1], bounds[0]=0, bounds[-1]=n_rows."""
     n = degree.shape[0]
@@ -63,26 +74,25 @@ class RowShard:
         ds = None if dst_scale is None else dst_scale.reshape(-1)[self.lo:self.hi].contiguous()
         return self.local.spmm(X, src_scale, ds, out=out)
 
-    def gather_rows(self, y_local: torch.Tensor, group=None, out: Optional[torch.Tensor] = None,
-                    async_op: bool = False):
+    def gather_rows(self, y_local: torch.Tensor, group=None, out: Optional[torch.Tensor] = None):
         """All-gather the per-rank row blocks into the full (n_dst, F) result."""
         F = y_local.shape[1]
         even = all(self.bounds[i + 1] - self.bounds[i] == self.max_rows for i in range(self.world))
         if even:
             if out is None:
                 out = torch.empty((self.n_dst, F), dtype=y_local.dtype, device=y_local.device)
-            work = dist.all_gather_into_tensor(out, y_local.contiguous(), group=group, async_op=async_op)
-            return (out, work) if async_op else out
+            _all_gather_into(out, y_local.contiguous(), group)
+            return out
         pad = torch.zeros((self.max_rows, F), dtype=y_local.dtype, device=y_local.device)
         pad[: y_local.shape[0]] = y_local
         buf = torch.empty((self.world * self.max_rows, F), dtype=y_local.dtype, device=y_local.device)
-        dist.all_gather_into_tensor(buf, pad, group=group)
+        _all_gather_into(buf, pad, group)
         if out is None:
             out = torch.empty((self.n_dst, F), dtype=y_local.dtype, device=y_local.device)
         for r in range(self.world):
             n = self.bounds[r + 1] - self.bounds[r]
             out[self.bounds[r]:self.bounds[r + 1]] = buf[r * self.max_rows: r * self.max_rows + n]
-        return (out, None) if async_op else out
+        return out
 
 
 class ShardedRelation:
