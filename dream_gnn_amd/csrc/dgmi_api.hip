@@ -150,6 +150,18 @@ DGMI_API int dgmi_spmm_csr_planned_f32(const int32_t* indptr, const int32_t* ind
   return from_hip(dgmi::spmm_csr_f32(a, as_stream(stream)));
 }
 
+DGMI_API int dgmi_gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
+                                    int64_t lda, int64_t Fa, const float* B, int64_t ldb, int64_t Fb,
+                                    float* out, int64_t ldo, dgmi_stream_t stream) {
+  if (E < 0 || Fa < 0 || Fb < 0) return DGMI_ERR_INVALID_ARG;
+  if (E > INT32_MAX || Fa + Fb > INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (E == 0 || Fa + Fb == 0) return DGMI_OK;
+  if (src == nullptr || dst == nullptr || out == nullptr) return DGMI_ERR_INVALID_ARG;
+  if ((Fa > 0 && A == nullptr) || (Fb > 0 && B == nullptr)) return DGMI_ERR_INVALID_ARG;
+  if (lda < Fa || ldb < Fb || ldo < Fa + Fb) return DGMI_ERR_INVALID_ARG;
+  return from_hip(dgmi::gather_concat_f32(src, dst, E, A, lda, Fa, B, ldb, Fb, out, ldo, as_stream(stream)));
+}
+
 DGMI_API int dgmi_gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,
                     dgmi_stream_t stream) {
   if (n < 0) return DGMI_ERR_INVALID_ARG;

@@ -1,0 +1,81 @@
+// dgmi_edge.hip — per-edge gather-concat for the MLP decoder (gfx950).
+//
+// Replaces graph.apply_edges(udf_u_mul_e) (reference layers.py:364,378-379): for every
+// decoder edge e, out[e] = cat(H_drug[src[e]], H_dis[dst[e]]).  The node tables are small
+// (N x F, L2 / Infinity-Cache resident) and the output is E x (Fa+Fb) fp32, so the kernel is
+// bound by the streaming HBM write: one 16-B store per lane, (Fa+Fb)/4 lanes per edge, whole
+// output rows written contiguously (F=128+128: one edge = one 1-KiB wave store).
+// Algorithmic bytes per edge: 4*(Fa+Fb) written + 4*(Fa+Fb) gathered + 8 of ids.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dgmi_kernels.h"
+
+namespace dgmi {
+namespace {
+
+constexpr int kBlock = 256;
+
+// 16-B path: Fa, Fb, lda, ldb, ldo multiples of 4 and 16-B aligned bases.  Thread t of the
+// grid handles float4 slot (t % W4) of edge (t / W4), W4 = (Fa+Fb)/4, grid-strided.
+__global__ __launch_bounds__(kBlock) void gather_concat_vec4_kernel(
+    const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t E,
+    const float* __restrict__ A, int64_t lda, int Fa4, const float* __restrict__ B, int64_t ldb,
+    int W4, float* __restrict__ out, int64_t ldo) {
+  const int64_t total = E * W4;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+    const int64_t e = t / W4;
+    const int c = (int)(t - e * W4);
+    float4 v;
+    if (c < Fa4)
+      v = *reinterpret_cast<const float4*>(A + (int64_t)src[e] * lda + 4 * c);
+    else
+      v = *reinterpret_cast<const float4*>(B + (int64_t)dst[e] * ldb + 4 * (c - Fa4));
+    *reinterpret_cast<float4*>(out + e * ldo + 4 * c) = v;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_concat_dword_kernel(
+    const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t E,
+    const float* __restrict__ A, int64_t lda, int Fa, const float* __restrict__ B, int64_t ldb,
+    int W, float* __restrict__ out, int64_t ldo) {
+  const int64_t total = E * W;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+    const int64_t e = t / W;
+    const int c = (int)(t - e * W);
+    out[e * ldo + c] = c < Fa ? A[(int64_t)src[e] * lda + c] : B[(int64_t)dst[e] * ldb + (c - Fa)];
+  }
+}
+
+inline unsigned grid_for(int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > 8192) b = 8192;  // 256 CUs x 8 blocks x 4: enough stores in flight, grid-stride the rest
+  return (unsigned)b;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+hipError_t gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
+                             int64_t lda, int64_t Fa, const float* B, int64_t ldb, int64_t Fb,
+                             float* out, int64_t ldo, hipStream_t s) {
+  if (E == 0 || Fa + Fb == 0) return hipSuccess;
+  const bool vec = (Fa % 4 == 0) && (Fb % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+                   (ldo % 4 == 0) && al16(A) && al16(B) && al16(out);
+  if (vec) {
+    const int W4 = (int)((Fa + Fb) / 4);
+    hipLaunchKernelGGL(gather_concat_vec4_kernel, dim3(grid_for(E * W4)), dim3(kBlock), 0, s, src,
+                       dst, E, A, lda, (int)(Fa / 4), B, ldb, W4, out, ldo);
+  } else {
+    const int W = (int)(Fa + Fb);
+    hipLaunchKernelGGL(gather_concat_dword_kernel, dim3(grid_for(E * W)), dim3(kBlock), 0, s, src,
+                       dst, E, A, lda, (int)Fa, B, ldb, W, out, ldo);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace dgmi

@@ -68,6 +68,11 @@ hipError_t csr_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
                             int32_t* eid, void* workspace, size_t* workspace_bytes,
                             hipStream_t s);
 
+// out[e] = cat(A[src[e]], B[dst[e]])   (dgmi_edge.hip)
+hipError_t gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
+                             int64_t lda, int64_t Fa, const float* B, int64_t ldb, int64_t Fb,
+                             float* out, int64_t ldo, hipStream_t s);
+
 hipError_t gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,
                       hipStream_t s);
 

@@ -166,6 +166,7 @@ class HeteroGraph:
             if r.src.dtype != torch.int32:
                 r.src, r.dst = r.src.to(torch.int32), r.dst.to(torch.int32)
                 r._csr = None
+                r._pairs = None
         return self
 
     def to(self, device) -> "HeteroGraph":
@@ -174,6 +175,7 @@ class HeteroGraph:
             if r.src.device != device:
                 r.src, r.dst = r.src.to(device), r.dst.to(device)
                 r._csr = None
+                r._pairs = None
         for store in self._ndata.values():
             for k, v in list(store.items()):
                 store[k] = v.to(device)
@@ -210,6 +212,13 @@ class HeteroGraph:
         if not hasattr(self, "edata"):
             self.edata = {}
         self.edata.update(udf(e))
+
+    def edge_pairs(self, etype=None) -> "ops.EdgePairs":
+        """Kernel-side view of one relation's edge list for the decoder gather-concat."""
+        rel = self[etype] if etype is not None else self._single()
+        if getattr(rel, "_pairs", None) is None:
+            rel._pairs = ops.EdgePairs(rel.src, rel.dst, rel.n_src, rel.n_dst, check_range=not rel.trusted)
+        return rel._pairs
 
     def _single(self) -> RelationGraph:
         if len(self._rels) != 1:

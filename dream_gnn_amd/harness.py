@@ -1,0 +1,110 @@
+"""Harness: the training / evaluation step *structure* of the reference, restated so the HIP
+path can be driven end to end on a box with neither DGL nor the reference (scope row H).
+
+Mirrors, by line:
+  * the augmentation defaults of ``train.py:238,267`` — ``edge_dropout`` on the encoder graph
+    (augmentation.py:13-89) and on the four sparse adjacencies (:92-124), ``feature_noise`` on
+    the four feature matrices (:208-241, scales 0.05 / sim 0.05 via augmentation.py:473-476);
+  * one optimisation step ``train.py:280-300`` — forward, ``BCEWithLogits + beta * (common_loss
+    drug + common_loss disease)``, backward, ``clip_grad_norm_``, optimiser step;
+  * the metric lines of ``evaluation.py:55-65`` — trapezoid AUROC and trapezoid PR-AUC
+    ``auc(recall, precision)`` (not average precision).
+Nothing here is on the hot path; it only calls it.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import graph as G
+from .model import common_loss
+
+
+def augment(batch: Dict, edge_dropout_rate: float = 0.1, feature_noise_scale: float = 0.05,
+            sim_noise_scale: float = 0.05, generator: Optional[torch.Generator] = None) -> Dict:
+    """``augment_graph_data(..., ['edge_dropout', 'feature_noise'])`` — augmentation.py:402-489.
+    The decoder graph is not augmented (train.py:270)."""
+    out = dict(batch)
+    out["enc_graph"] = G.random_edge_dropout(batch["enc_graph"], edge_dropout_rate, generator)
+    for k in ("drug_graph", "disease_graph", "drug_feature_graph", "disease_feature_graph"):
+        if batch.get(k) is not None:
+            out[k] = G.random_edge_dropout_sparse(batch[k], edge_dropout_rate, generator)
+    for k, scale in (("drug_feat", feature_noise_scale), ("disease_feat", feature_noise_scale),
+                     ("drug_sim_feat", sim_noise_scale), ("disease_sim_feat", sim_noise_scale)):
+        if batch.get(k) is not None:
+            x = batch[k]
+            noise = torch.randn(x.shape, dtype=x.dtype, device=x.device, generator=generator)
+            out[k] = x + noise * scale
+    return out
+
+
+def forward_loss(net, batch: Dict, labels: torch.Tensor, beta: float):
+    """train.py:280-294."""
+    pred, drug_out, drug_sim_out, dis_out, dis_sim_out = net(
+        batch["enc_graph"], batch["dec_graph"], batch["drug_graph"], batch["drug_sim_feat"], batch["drug_feat"],
+        batch["disease_graph"], batch["disease_sim_feat"], batch["disease_feat"],
+        batch.get("drug_feature_graph"), batch.get("disease_feature_graph"), False)
+    pred = pred.squeeze(-1)
+    rel = nn.functional.binary_cross_entropy_with_logits(pred, labels)
+    loss = rel + beta * (common_loss(drug_out, drug_sim_out) + common_loss(dis_out, dis_sim_out))
+    return loss, pred
+
+
+def train_step(net, optimizer, batch: Dict, labels: torch.Tensor, beta: float = 0.1, grad_clip: float = 1.0,
+               do_augment: bool = True, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """One iteration of train.py:249-300.  Returns the (detached) total loss."""
+    net.train()
+    step_batch = augment(batch, generator=generator) if do_augment else batch
+    loss, _ = forward_loss(net, step_batch, labels, beta)
+    optimizer.zero_grad()
+    loss.backward()
+    nn.utils.clip_grad_norm_(net.parameters(), grad_clip)
+    optimizer.step()
+    return loss.detach()
+
+
+def _binary_clf_curve(y_true: np.ndarray, y_score: np.ndarray):
+    order = np.argsort(-y_score, kind="mergesort")
+    y_score, y_true = y_score[order], y_true[order]
+    distinct = np.where(np.diff(y_score))[0]
+    idx = np.r_[distinct, y_true.size - 1]
+    tps = np.cumsum(y_true, dtype=np.float64)[idx]
+    fps = 1 + idx - tps
+    return fps, tps
+
+
+def _trapz(y, x):
+    return float(np.sum((x[1:] - x[:-1]) * (y[1:] + y[:-1]) / 2.0))
+
+
+def auroc_aupr(y_true, y_score):
+    """``metrics.auc(*roc_curve)`` and ``metrics.auc(recall, precision)`` — evaluation.py:60-65."""
+    y_true = np.asarray(y_true, dtype=np.float64).reshape(-1)
+    y_score = np.asarray(y_score, dtype=np.float64).reshape(-1)
+    fps, tps = _binary_clf_curve(y_true, y_score)
+    # ROC: curve starts at (0, 0); dropping collinear points (sklearn's drop_intermediate) does
+    # not change the trapezoid area
+    fpr = np.r_[0.0, fps] / fps[-1]
+    tpr = np.r_[0.0, tps] / tps[-1]
+    auroc = _trapz(tpr, fpr)
+    # PR: one point per distinct threshold, plus the (recall 0, precision 1) end point
+    ps = tps + fps
+    precision = np.divide(tps, ps, out=np.zeros_like(tps), where=ps != 0)
+    recall = tps / tps[-1]
+    precision = np.r_[precision[::-1], 1.0]
+    recall = np.r_[recall[::-1], 0.0]
+    aupr = -_trapz(precision, recall)  # recall is decreasing
+    return auroc, aupr
+
+
+@torch.no_grad()
+def evaluate(net, batch: Dict, labels: torch.Tensor):
+    """evaluation.py:44-65: eval-mode forward on the un-augmented graphs, then the two areas."""
+    net.eval()
+    pred, *_ = net(batch["enc_graph"], batch["dec_graph"], batch["drug_graph"], batch["drug_sim_feat"],
+                   batch["drug_feat"], batch["disease_graph"], batch["disease_sim_feat"], batch["disease_feat"],
+                   batch.get("drug_feature_graph"), batch.get("disease_feature_graph"))
+    return auroc_aupr(labels.cpu().numpy(), pred.view(-1).cpu().numpy())

@@ -313,3 +313,86 @@ def spmm_csr(g: CSRGraph, X: torch.Tensor, src_scale: Optional[torch.Tensor] = N
     if src_scale is not None and src_scale.requires_grad or dst_scale is not None and dst_scale.requires_grad:
         raise RuntimeError("spmm_csr: gradients w.r.t. the diagonal scales are not part of the path")
     return _SpMM.apply(X, g, src_scale, dst_scale)
+
+
+# ---------------------------------------------------------------------------------------------
+# (f2) decoder edge gather-concat: graph.apply_edges(udf_u_mul_e) — layers.py:364,378-379
+# ---------------------------------------------------------------------------------------------
+def gather_concat_raw(src, dst, A, B, out=None) -> torch.Tensor:
+    """``out[e] = cat(A[src[e]], B[dst[e]])`` through ``dgmi_gather_concat_f32`` (no autograd)."""
+    dev = _require_device(src, dst, A, B, out)
+    _check(src, torch.int32, "src", 1)
+    _check(dst, torch.int32, "dst", 1)
+    if src.shape != dst.shape:
+        raise RuntimeError("src/dst length mismatch")
+    A, n_a, Fa, lda = _prep_dense(A)
+    B, n_b, Fb, ldb = _prep_dense(B)
+    E = src.shape[0]
+    if out is None:
+        out = torch.empty((E, Fa + Fb), dtype=torch.float32, device=dev)
+    elif out.dtype != torch.float32 or tuple(out.shape) != (E, Fa + Fb) or not out.is_contiguous():
+        raise RuntimeError("out must be a contiguous float32 (%d, %d) tensor" % (E, Fa + Fb))
+    with _guard(dev):
+        _lib.check(_L.dgmi_gather_concat_f32(_ptr(src), _ptr(dst), E, _ptr(A), lda, Fa, _ptr(B), ldb, Fb,
+                                             _ptr(out), max(Fa + Fb, 1), _stream(dev)), "dgmi_gather_concat_f32")
+    return out
+
+
+class EdgePairs:
+    """The decoder graph's edge list (data_loader.py:492-509) in the layout the kernels read:
+    int32 ``src``/``dst`` ids plus, built lazily for the backward, the two CSRs whose
+    ``indices`` are *edge ids* grouped by source node and by destination node (so that
+    ``copy_e -> sum`` is the SpMM kernel gathering rows of d_out)."""
+
+    def __init__(self, src: torch.Tensor, dst: torch.Tensor, n_src: int, n_dst: int, check_range: bool = True):
+        _require_device(src, dst)
+        self.src = src.to(torch.int32).contiguous()
+        self.dst = dst.to(torch.int32).contiguous()
+        self.n_src, self.n_dst = int(n_src), int(n_dst)
+        self.E = int(self.src.shape[0])
+        if check_range and self.E:
+            lo = torch.stack([self.src.min(), self.dst.min()]).min()
+            hi_s, hi_d = self.src.max(), self.dst.max()
+            lo, hi_s, hi_d = (int(v) for v in torch.stack([lo, hi_s, hi_d]).tolist())
+            if lo < 0 or hi_s >= self.n_src or hi_d >= self.n_dst:
+                raise RuntimeError("decoder edge id out of range")
+        self._by_src = self._by_dst = None
+
+    def _group(self, key, n):
+        iota = torch.arange(self.E, dtype=torch.int32, device=key.device)
+        g = CSRGraph(key, iota, n, self.E, check_range=False)
+        return g
+
+    def by_src(self) -> "CSRGraph":
+        if self._by_src is None:
+            self._by_src = self._group(self.src, self.n_src)
+        return self._by_src
+
+    def by_dst(self) -> "CSRGraph":
+        if self._by_dst is None:
+            self._by_dst = self._group(self.dst, self.n_dst)
+        return self._by_dst
+
+
+class _GatherConcat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, B, pairs: EdgePairs):
+        ctx.pairs = pairs
+        ctx.Fa, ctx.Fb = A.shape[1], B.shape[1]
+        return gather_concat_raw(pairs.src, pairs.dst, A, B)
+
+    @staticmethod
+    def backward(ctx, dOut):
+        pairs, Fa, Fb = ctx.pairs, ctx.Fa, ctx.Fb
+        dOut = dOut.contiguous()
+        dA = dB = None
+        if ctx.needs_input_grad[0]:  # dA[u] = sum over edges leaving u of d_out[e, :Fa]
+            dA = pairs.by_src().spmm(dOut[:, :Fa])
+        if ctx.needs_input_grad[1]:  # dB[v] = sum over edges entering v of d_out[e, Fa:]
+            dB = pairs.by_dst().spmm(dOut[:, Fa:])
+        return dA, dB, None
+
+
+def gather_concat(pairs: EdgePairs, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """Differentiable ``cat(A[src], B[dst])`` over the decoder edges."""
+    return _GatherConcat.apply(A, B, pairs)

@@ -11,6 +11,7 @@
  *   (f1)   data_loader.py:448 / augmentation.py:65  dgl.heterograph(...) + DGL's lazy
  *                             COO->CSR build (stable by destination row)
  *   (f2)   layers.py:364,378  graph.apply_edges(udf_u_mul_e)  (cat(h_src, h_dst) per edge)
+ *                             -> DGL Python-UDF path (two index_selects + cat)
  * Every entry point below names the call site it replaces.
  *
  * Conventions
@@ -37,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 3
+#define DGMI_ABI_VERSION 4
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -157,6 +158,21 @@ DGMI_API int dgmi_spmm_csr_planned_f32(const int32_t* indptr, const int32_t* ind
  */
 DGMI_API int dgmi_gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,
                     dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
+ * (f2) Per-edge gather-concat: out[e, 0:Fa] = A[src[e], :], out[e, Fa:Fa+Fb] = B[dst[e], :].
+ * Replaces graph.apply_edges(udf_u_mul_e) of the MLP decoder (layers.py:364,378-379:
+ * th.cat([edges.src['h'], edges.dst['h']], 1)), which DGL runs as two index_selects and a
+ * cat.  Pure copies: the result is bit-identical to the reference's.  A is (n_a, Fa) with
+ * leading dimension lda, B is (n_b, Fb) with ldb, out is (E, Fa+Fb) with ldo >= Fa+Fb.
+ * The backward (copy_e -> sum onto the source / destination nodes) is dgmi_spmm_csr_f32 on
+ * the CSR whose `indices` are edge ids (dgmi_csr_from_coo_i32(src, iota, ...)) with
+ * X = d_out (+ column offset), ldx = ldo.
+ */
+DGMI_API int dgmi_gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E,
+                                    const float* A, int64_t lda, int64_t Fa, const float* B,
+                                    int64_t ldb, int64_t Fb, float* out, int64_t ldo,
+                                    dgmi_stream_t stream);
 
 #ifdef __cplusplus
 }

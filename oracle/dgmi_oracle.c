@@ -178,6 +178,19 @@ void oracle_gather_f32(const float* in, const int32_t* perm, int64_t n, float* o
   for (int64_t p = 0; p < n; ++p) out[p] = in[perm[p]];
 }
 
+/* ------------------------------------------------------------------------
+ * Decoder edge gather: out[e] = cat(A[src[e]], B[dst[e]]) — the reference's
+ * udf_u_mul_e under graph.apply_edges (layers.py:364,378-379).
+ */
+void oracle_gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
+                              int64_t lda, int64_t Fa, const float* B, int64_t ldb, int64_t Fb,
+                              float* out, int64_t ldo) {
+  for (int64_t e = 0; e < E; ++e) {
+    memcpy(out + e * ldo, A + (int64_t)src[e] * lda, (size_t)Fa * sizeof(float));
+    memcpy(out + e * ldo + Fa, B + (int64_t)dst[e] * ldb, (size_t)Fb * sizeof(float));
+  }
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -63,6 +63,9 @@ def lib() -> ctypes.CDLL:
                                           ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]
         L.oracle_gather_f32.restype = None
         L.oracle_gather_f32.argtypes = [_f32p, _i32p, ctypes.c_int64, _f32p]
+        L.oracle_gather_concat_f32.restype = None
+        L.oracle_gather_concat_f32.argtypes = [_i32p, _i32p, ctypes.c_int64, _f32p, ctypes.c_int64, ctypes.c_int64,
+                                               _f32p, ctypes.c_int64, ctypes.c_int64, _f32p, ctypes.c_int64]
         L.oracle_max_threads.restype = ctypes.c_int
         _lib = L
     return _lib
@@ -142,6 +145,19 @@ def spmm_coo(row, col, vals, X, n_rows):
     lib().oracle_spmm_coo_f32(_p(row, _i64p), _p(col, _i64p), _p(vals, _f32p), row.shape[0], _p(X, _f32p), F,
                               _p(Y, _f32p), F, int(n_rows), F)
     return Y
+
+
+def gather_concat(src, dst, A, B):
+    """``cat(A[src[e]], B[dst[e]])`` per edge — udf_u_mul_e (layers.py:364,378-379)."""
+    src = _c(src, np.int32)
+    dst = _c(dst, np.int32)
+    A = _c(A, np.float32)
+    B = _c(B, np.float32)
+    E, Fa, Fb = src.shape[0], A.shape[1], B.shape[1]
+    out = np.empty((E, Fa + Fb), np.float32)
+    lib().oracle_gather_concat_f32(_p(src, _i32p), _p(dst, _i32p), E, _p(A, _f32p), Fa, Fa, _p(B, _f32p), Fb, Fb,
+                                   _p(out, _f32p), Fa + Fb)
+    return out
 
 
 def transpose_coo(row, col):

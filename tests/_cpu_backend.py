@@ -32,6 +32,14 @@ def spmm_csr_raw(indptr, indices, vals, X, src_scale=None, dst_scale=None, out=N
     return y
 
 
+def gather_concat_raw(src, dst, A, B, out=None):
+    y = torch.from_numpy(O.gather_concat(src.numpy(), dst.numpy(), A.detach().numpy(), B.detach().numpy()))
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx):
     return spmm_csr_raw(indptr, indices, vals, X, src_scale, dst_scale, out=out)
 
@@ -40,10 +48,12 @@ def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan,
 def patched():
     from dream_gnn_amd import ops
 
-    names = ("csr_from_coo", "gather_f32", "spmm_csr_raw", "_launch_spmm", "_require_device", "build_plan")
+    names = ("csr_from_coo", "gather_f32", "spmm_csr_raw", "_launch_spmm", "_require_device", "build_plan",
+             "gather_concat_raw")
     saved = {k: getattr(ops, k) for k in names}
     ops.csr_from_coo, ops.gather_f32, ops.spmm_csr_raw = csr_from_coo, gather_f32, spmm_csr_raw
     ops._launch_spmm = _launch_spmm
+    ops.gather_concat_raw = gather_concat_raw
     ops._require_device = lambda *ts: next((t.device for t in ts if t is not None), None)
     ops.build_plan = lambda indptr, nnz, chunk=None: None  # launch plans are a device-side concern
     try:

@@ -16,7 +16,8 @@ def _declared():
 
 
 def test_header_declares_the_expected_entry_points():
-    assert _declared() == ["dgmi_abi_version", "dgmi_csr_from_coo_i32", "dgmi_device_ok", "dgmi_gather_f32",
+    assert _declared() == ["dgmi_abi_version", "dgmi_csr_from_coo_i32", "dgmi_device_ok", "dgmi_gather_concat_f32",
+                           "dgmi_gather_f32",
                            "dgmi_spmm_csr_f32", "dgmi_spmm_csr_planned_f32", "dgmi_spmm_default_chunk",
                            "dgmi_spmm_partials_bytes", "dgmi_spmm_plan_build", "dgmi_spmm_plan_bytes",
                            "dgmi_status_string"]
@@ -67,6 +68,9 @@ def test_argument_validation_returns_codes_without_a_gpu():
     assert L.dgmi_spmm_plan_build(None, -1, 0, 64, None, 0, None, ctypes.byref(need), None) == -1
     assert L.dgmi_spmm_csr_planned_f32(16, 16, None, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 7, 16, 16, 1 << 20, None) == -1
     assert L.dgmi_spmm_csr_planned_f32(16, 16, None, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 64, 16, 16, 0, None) == -3
+    assert L.dgmi_gather_concat_f32(None, None, -1, None, 4, 4, None, 4, 4, None, 8, None) == -1
+    assert L.dgmi_gather_concat_f32(16, 16, 3, 16, 4, 4, 16, 4, 4, 16, 7, None) == -1  # ldo < Fa+Fb
+    assert L.dgmi_gather_concat_f32(None, None, 0, None, 4, 4, None, 4, 4, None, 8, None) == 0
     assert L.dgmi_gather_f32(None, None, -3, None, None) == -1
     assert L.dgmi_gather_f32(None, None, 0, None, None) == 0
 

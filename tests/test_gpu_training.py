@@ -1,0 +1,83 @@
+"""Accuracy-clause replacement: the lrssl dataset and DGL are absent, so the
+'AUROC/AUPR within +-0.001 of the reference' clause is checked as: on lrssl-shaped synthetic
+data, N optimisation steps through the HIP path (cuda:0) versus the same steps with the CPU
+oracle patched in as the op backend, from identical initial weights and without stochastic
+layers: loss curves within 1e-4, final AUROC / AUPR within 0.001."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import _cpu_backend
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(dev, nd=151, ns=113, emb=48):
+    from dream_gnn_amd import graph as G, synth
+
+    rng = np.random.default_rng(5)
+    pairs = np.array([(d, s) for d in range(nd) for s in range(ns)])
+    pairs = pairs[rng.random(len(pairs)) < 0.9]
+    labels = (rng.random(len(pairs)) < 0.03).astype(np.float32)
+    labels[:2] = [0, 1]
+    d, s, v = (torch.from_numpy(pairs[:, 0]), torch.from_numpy(pairs[:, 1]), torch.from_numpy(labels))
+    batch = {"enc_graph": G.build_enc_graph(d, s, v, nd, ns, device=dev).int(),
+             "dec_graph": G.build_dec_graph(d, s, nd, ns, device=dev).int()}
+    gen = torch.Generator().manual_seed(9)
+    for key, n in (("drug", nd), ("disease", ns)):
+        sim = torch.rand(n, n, generator=gen)
+        batch[key + "_sim_feat"] = ((sim + sim.t()) / 2).to(dev)
+        batch[key + "_feat"] = torch.nn.functional.normalize(torch.randn(n, emb, generator=gen)).to(dev)
+        for gname, seed in ((key + "_graph", 1), (key + "_feature_graph", 2)):
+            A = (torch.rand(n, n, generator=gen) < 6.0 / n).float()
+            A = A + A.t() + torch.eye(n)
+            A = A / A.sum(1, keepdim=True)
+            batch[gname] = A.to_sparse().to(dev)
+    args = types.SimpleNamespace(rating_vals=[0, 1], src_in_units=emb, dst_in_units=emb, gcn_agg_units=96,
+                                 gcn_out_units=16, dropout=0.0, gcn_agg_accum="sum", model_activation="leaky",
+                                 share_param=True, device=None, layers=3, fdim_drug=nd, fdim_disease=ns,
+                                 nhid1=32, nhid2=16, attention_dropout=0.0)
+    return batch, v.to(dev), args
+
+
+def _run(dev, steps, state=None):
+    from dream_gnn_amd import harness as H, model as M
+
+    batch, labels, args = _problem(dev)
+    torch.manual_seed(123)
+    net = M.Net(args)
+    if state is not None:
+        net.load_state_dict(state)
+    init = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-5)
+    losses = [float(H.train_step(net, opt, batch, labels, beta=0.1, do_augment=False)) for _ in range(steps)]
+    return losses, H.evaluate(net, batch, labels), init
+
+
+def test_hip_path_tracks_cpu_oracle_path(oracle, dev):
+    steps = 25
+    gpu_losses, (gpu_auroc, gpu_aupr), init = _run(dev, steps)
+    with _cpu_backend.patched():
+        cpu_losses, (cpu_auroc, cpu_aupr), _ = _run(torch.device("cpu"), steps, state=init)
+    assert max(abs(a - b) for a, b in zip(gpu_losses, cpu_losses)) <= 1e-4, (gpu_losses[-3:], cpu_losses[-3:])
+    assert gpu_losses[-1] < gpu_losses[0]
+    assert abs(gpu_auroc - cpu_auroc) <= 1e-3 and abs(gpu_aupr - cpu_aupr) <= 1e-3
+
+
+def test_training_step_with_augmentation_runs_on_device(dev):
+    """The reference augments unconditionally every iteration (train.py:267): encoder-graph and
+    sparse-adjacency edge dropout rebuild 4 + 4 CSRs (and their transposes) per step on the device."""
+    from dream_gnn_amd import harness as H, model as M
+
+    batch, labels, args = _problem(dev)
+    args.dropout, args.attention_dropout = 0.1, 0.1
+    torch.manual_seed(1)
+    net = M.Net(args).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-5)
+    losses = [float(H.train_step(net, opt, batch, labels, beta=0.1)) for _ in range(10)]
+    assert all(np.isfinite(losses))
+    auroc, aupr = H.evaluate(net, batch, labels)
+    assert 0 <= auroc <= 1 and 0 <= aupr <= 1

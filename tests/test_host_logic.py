@@ -116,3 +116,49 @@ def test_uncoalesced_duplicates_sum_like_torch_spmm():
     gc = L.GraphConvolution(6, 6, bias=False)
     gc.weight.data = torch.eye(6)
     assert torch.allclose(gc(x, adj), torch.spmm(adj, x), atol=1e-6)
+
+
+def test_metric_lines_match_evaluation_py():
+    from dream_gnn_amd.harness import auroc_aupr
+
+    g = C.load("metrics")
+    for i in range(3):
+        auroc, aupr = auroc_aupr(g["true%d" % i], g["score%d" % i])
+        assert abs(auroc - g["auroc"][i]) < 1e-12 and abs(aupr - g["aupr"][i]) < 1e-12
+
+
+def test_common_loss_matches_utils_py():
+    from dream_gnn_amd.model import common_loss
+
+    g = C.load("common_loss")
+    got = common_loss(torch.from_numpy(g["e1"]), torch.from_numpy(g["e2"]))
+    assert abs(float(got) - float(g["loss"])) < 1e-7
+
+
+def test_train_step_structure_on_cpu_backend():
+    """augmentation -> forward -> loss -> backward -> clip -> Adam (train.py:249-300) runs through
+    the drop-in modules; edge dropout rebuilds the graphs every step."""
+    from dream_gnn_amd import graph as G, harness as H, model as M
+
+    g = C.load("net_mini")
+    nd, ns = int(g["n_drug"]), int(g["n_dis"])
+    args = C.net_args(g)
+    args.dropout = 0.1
+    torch.manual_seed(0)
+    net = C.load_sd(M.Net(args), g, CPU)
+    batch = {"enc_graph": C.build_enc(g, CPU),
+             "dec_graph": G.build_dec_graph(torch.from_numpy(g["dec_src"]), torch.from_numpy(g["dec_dst"]), nd, ns).int(),
+             "drug_graph": C.sparse(g, "drug_graph", nd, nd, CPU), "disease_graph": C.sparse(g, "dis_graph", ns, ns, CPU),
+             "drug_feature_graph": C.sparse(g, "drug_fg", nd, nd, CPU), "disease_feature_graph": C.sparse(g, "dis_fg", ns, ns, CPU),
+             "drug_feat": torch.from_numpy(g["drug_feat"]), "disease_feat": torch.from_numpy(g["dis_feat"]),
+             "drug_sim_feat": torch.from_numpy(g["drug_sim"]), "disease_sim_feat": torch.from_numpy(g["dis_sim"])}
+    labels = torch.from_numpy(g["values"])
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-5)  # train.py:217
+    losses = [float(H.train_step(net, opt, batch, labels, beta=0.1)) for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    aug = H.augment(batch)
+    assert aug["enc_graph"].number_of_edges("0") == max(1, int(batch["enc_graph"].number_of_edges("0") * 0.9))
+    assert aug["drug_graph"]._values().shape[0] == max(1, int(batch["drug_graph"]._values().shape[0] * 0.9))
+    assert aug["dec_graph"] is batch["dec_graph"] and not torch.equal(aug["drug_feat"], batch["drug_feat"])
+    auroc, aupr = H.evaluate(net, batch, labels)
+    assert 0.0 <= auroc <= 1.0 and 0.0 <= aupr <= 1.0

@@ -78,3 +78,18 @@ if "widths" in which:
         X = torch.randn(n_src, F, device=dev)
         report("uniform 10M", g, X, F)
         del X
+if "decoder" in which:
+    for nd, ns, E, tag in ((763, 681, 467_000, "lrssl-shape"), (100_000, 50_000, 10_000_000, "cfg4")):
+        s = torch.randint(0, nd, (E,), generator=gen, device=dev, dtype=torch.int32)
+        d = torch.randint(0, ns, (E,), generator=gen, device=dev, dtype=torch.int32)
+        A, B = torch.randn(nd, 128, device=dev), torch.randn(ns, 128, device=dev)
+        out = torch.empty(E, 256, device=dev)
+        ms = timeit(lambda: ops.gather_concat_raw(s, d, A, B, out=out))
+        ms_t = timeit(lambda: torch.cat([A.index_select(0, s.long()), B.index_select(0, d.long())], 1))
+        pairs = ops.EdgePairs(s, d, nd, ns)
+        dO = torch.randn(E, 256, device=dev)
+        gs, gd = pairs.by_src(), pairs.by_dst()
+        ms_b = timeit(lambda: (gs.spmm(dO[:, :128]), gd.spmm(dO[:, 128:])))
+        da = torch.zeros(nd, 128, device=dev); db = torch.zeros(ns, 128, device=dev)
+        ms_bt = timeit(lambda: (da.index_add_(0, s.long(), dO[:, :128]), db.index_add_(0, d.long(), dO[:, 128:])))
+        print(f"decoder gather-concat {tag} E={E}: hip {ms*1e3:.1f} us ({E*256*4*2/ms/1e6:.0f} GB/s r+w) vs torch index_select+cat {ms_t*1e3:.1f} us | bwd hip {ms_b*1e3:.1f} us vs torch index_add {ms_bt*1e3:.1f} us", flush=True)
