@@ -36,6 +36,32 @@ __global__ __launch_bounds__(kBlock) void gather_concat_vec4_kernel(
   }
 }
 
+// Same, for W4 dividing the block size (every power-of-two width up to 1024 floats, e.g. the
+// model's 128+128): the lane's column and edge offset are fixed, so the loop carries no division.
+__global__ __launch_bounds__(kBlock) void gather_concat_vec4_pow2_kernel(
+    const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t E,
+    const float* __restrict__ A, int64_t lda, int Fa4, const float* __restrict__ B, int64_t ldb,
+    int W4, float* __restrict__ out, int64_t ldo) {
+  const int c = threadIdx.x % W4;
+  const int epb = kBlock / W4;  // edges per block iteration
+  const bool from_a = c < Fa4;
+  const int32_t* __restrict__ ids = from_a ? src : dst;
+  const float* __restrict__ tab = from_a ? A + 4 * c : B + 4 * (c - Fa4);
+  const int64_t ld = from_a ? lda : ldb;
+  float* __restrict__ o = out + 4 * c;
+  const int64_t stride = (int64_t)gridDim.x * epb;
+  int64_t e = (int64_t)blockIdx.x * epb + threadIdx.x / W4;
+  // two edges in flight per lane
+  for (; e + stride < E; e += 2 * stride) {
+    const int32_t i0 = ids[e], i1 = ids[e + stride];
+    const float4 v0 = *reinterpret_cast<const float4*>(tab + (int64_t)i0 * ld);
+    const float4 v1 = *reinterpret_cast<const float4*>(tab + (int64_t)i1 * ld);
+    *reinterpret_cast<float4*>(o + e * ldo) = v0;
+    *reinterpret_cast<float4*>(o + (e + stride) * ldo) = v1;
+  }
+  if (e < E) *reinterpret_cast<float4*>(o + e * ldo) = *reinterpret_cast<const float4*>(tab + (int64_t)ids[e] * ld);
+}
+
 __global__ __launch_bounds__(kBlock) void gather_concat_dword_kernel(
     const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t E,
     const float* __restrict__ A, int64_t lda, int Fa, const float* __restrict__ B, int64_t ldb,
@@ -68,6 +94,12 @@ hipError_t gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, 
                    (ldo % 4 == 0) && al16(A) && al16(B) && al16(out);
   if (vec) {
     const int W4 = (int)((Fa + Fb) / 4);
+    if (W4 <= kBlock && kBlock % W4 == 0) {
+      const int64_t blocks = (E * W4 + kBlock - 1) / kBlock;
+      hipLaunchKernelGGL(gather_concat_vec4_pow2_kernel, dim3(grid_for(blocks * kBlock / 2)),
+                         dim3(kBlock), 0, s, src, dst, E, A, lda, (int)(Fa / 4), B, ldb, W4, out, ldo);
+      return hipGetLastError();
+    }
     hipLaunchKernelGGL(gather_concat_vec4_kernel, dim3(grid_for(E * W4)), dim3(kBlock), 0, s, src,
                        dst, E, A, lda, (int)(Fa / 4), B, ldb, W4, out, ldo);
   } else {

@@ -167,6 +167,7 @@ class HeteroGraph:
                 r.src, r.dst = r.src.to(torch.int32), r.dst.to(torch.int32)
                 r._csr = None
                 r._pairs = None
+                self.__dict__.pop("_fused", None)
         return self
 
     def to(self, device) -> "HeteroGraph":
@@ -176,6 +177,7 @@ class HeteroGraph:
                 r.src, r.dst = r.src.to(device), r.dst.to(device)
                 r._csr = None
                 r._pairs = None
+                self.__dict__.pop("_fused", None)
         for store in self._ndata.values():
             for k, v in list(store.items()):
                 store[k] = v.to(device)
@@ -212,6 +214,33 @@ class HeteroGraph:
         if not hasattr(self, "edata"):
             self.edata = {}
         self.edata.update(udf(e))
+
+    def fused_relations(self, dst_type: str):
+        """All relations that end in ``dst_type`` as ONE destination-major CSR (f3).
+
+        With R relations r = 0..R-1 (canonical order) from the same source type, edge (u -> v)
+        of relation r becomes column ``R*u + r``: the row sum over the fused CSR is then the
+        hetero ``'sum'`` aggregate of layers.py:98,129 when the source features are laid out
+        ``[u][r][:]`` (one GEMM ``X @ [W_0 | ... | W_{R-1}]``).  In-row order: relation 0's
+        edges in their input order, then relation 1's, ...  Returns ``(csr, [canonical...])`` or
+        ``None`` if the relations do not share one source type.
+        """
+        cache = self.__dict__.setdefault("_fused", {})
+        if dst_type in cache:
+            return cache[dst_type]
+        cans = [c for c in self._rels if c[2] == dst_type]
+        out = None
+        if cans and len({c[0] for c in cans}) == 1 and len({self._rels[c].src.device for c in cans}) == 1:
+            R = len(cans)
+            rels = [self._rels[c] for c in cans]
+            n_src, n_dst = rels[0].n_src, rels[0].n_dst
+            if R * n_src < 2 ** 31 - 1:
+                dst = torch.cat([r.dst.to(torch.int32) for r in rels])
+                src = torch.cat([r.src.to(torch.int32) * R + i for i, r in enumerate(rels)])
+                csr = ops.CSRGraph(dst, src, n_dst, R * n_src, check_range=not all(r.trusted for r in rels))
+                out = (csr, cans)
+        cache[dst_type] = out
+        return out
 
     def edge_pairs(self, etype=None) -> "ops.EdgePairs":
         """Kernel-side view of one relation's edge list for the decoder gather-concat."""
@@ -324,3 +353,59 @@ def random_edge_dropout_sparse(adj: torch.Tensor, dropout_rate: float = 0.1,
     out = torch.sparse_coo_tensor(idx[:, perm], val[perm], adj.shape, device=adj.device)
     out._dgmi_trusted = True  # a subset of a valid adjacency: adjacency_csr skips the id re-check (no host sync)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# (f4) similarity / feature kNN graph construction on the device
+# ---------------------------------------------------------------------------------------------
+def _normalized_adjacency(rows: torch.Tensor, cols: torch.Tensor, n: int, symm: bool) -> torch.Tensor:
+    """data_loader.py:297-308 + utils.py:11-27 after the neighbour choice: ones COO ->
+    (A + A^T if symm) -> + I -> D^-1 (.) -> sparse COO fp32, entries row-major sorted."""
+    eye = torch.arange(n, device=rows.device)
+    if symm:
+        r = torch.cat([rows, cols, eye])
+        c = torch.cat([cols, rows, eye])
+    else:
+        r = torch.cat([rows, eye])
+        c = torch.cat([cols, eye])
+    v = torch.ones(r.numel(), dtype=torch.float64, device=rows.device)
+    adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n)).coalesce()
+    idx, val = adj.indices(), adj.values()
+    rowsum = torch.zeros(n, dtype=torch.float64, device=rows.device).index_add_(0, idx[0], val)
+    inv = torch.where(rowsum != 0, 1.0 / rowsum, torch.zeros_like(rowsum))  # utils.py:14-15
+    out = torch.sparse_coo_tensor(idx, (val * inv[idx[0]]).to(torch.float32), (n, n))
+    out._dgmi_trusted = True
+    return out
+
+
+def similarity_graph(sim: torch.Tensor, k: int, symm: bool = True) -> torch.Tensor:
+    """``DrugDataLoader._create_similarity_graph`` (data_loader.py:278-310) on the device.
+
+    The k largest similarities per row (``argpartition(-sim, kth=k)[:, :k]``, usually including
+    the node itself) become unit edges; then symmetrise, add I, row-normalise.  Ties at the k-th
+    value are broken arbitrarily upstream (argpartition) and here (topk).
+    """
+    n = sim.shape[0]
+    k_actual = min(k, n - 1)
+    nbr = torch.topk(sim, k_actual, dim=1).indices
+    rows = torch.arange(n, device=sim.device).repeat_interleave(k_actual)
+    return _normalized_adjacency(rows, nbr.reshape(-1), n, symm)
+
+
+def feature_similarity_graph(features: torch.Tensor, k: int, symm: bool = True,
+                             block_rows: int = 8192) -> torch.Tensor:
+    """``_create_feature_similarity_graph`` (data_loader.py:312-344): cosine-similarity kNN graph
+    from embeddings, blocked over rows so the N x N similarity matrix is never materialised
+    (an 8192-row block against 100k columns is 3.3 GB of fp32, reduced to k ids per row at once).
+    """
+    n = features.shape[0]
+    k_actual = min(k, n - 1)
+    norms = features.norm(dim=1, keepdim=True)
+    norms = torch.where(norms == 0, torch.full_like(norms, 1e-10), norms)  # data_loader.py:334-335
+    xn = features / norms
+    nbr = torch.empty((n, k_actual), dtype=torch.int64, device=features.device)
+    for lo in range(0, n, block_rows):
+        hi = min(lo + block_rows, n)
+        nbr[lo:hi] = torch.topk(xn[lo:hi] @ xn.t(), k_actual, dim=1).indices
+    rows = torch.arange(n, device=features.device).repeat_interleave(k_actual)
+    return _normalized_adjacency(rows, nbr.reshape(-1), n, symm)

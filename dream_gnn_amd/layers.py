@@ -237,6 +237,11 @@ class GCMCLayer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
+    #: f3 — run all relation slices of one destination type as a single GEMM + a single SpMM
+    #: launch (hetero 'sum' accumulated in the kernel's registers).  Set False to go through
+    #: HeteroGraphConv one slice at a time, as the reference does.
+    fuse_relations = True
+
     def forward(self, graph, drug_feat=None, dis_feat=None, Two_Stage=False):
         # basis decomposition W_r = sum_b att[r,b] * basis[b]   (layers.py:120-121)
         self.W = torch.matmul(self.att, self.basis.view(self.basis_units, -1)).view(
@@ -247,10 +252,61 @@ class GCMCLayer(nn.Module):
             w = self.W[i] if self.W_r is not None else None
             mod_args[name] = (w, Two_Stage)
             mod_args["rev-%s" % name] = (w, Two_Stage)
-        out = self.conv(graph, {"drug": drug_feat, "disease": dis_feat}, mod_args=mod_args)
+        inputs = {"drug": drug_feat, "disease": dis_feat}
+        out = self._fused_conv(graph, inputs, mod_args) if self.fuse_relations and self.agg == "sum" else None
+        if out is None:
+            out = self.conv(graph, inputs, mod_args=mod_args)
         drug = self.dropout(self.agg_act(out["drug"]))
         dis = self.dropout(self.agg_act(out["disease"]))
         return self.ifc(drug), self.ufc(dis)
+
+    def _fused_conv(self, graph, inputs, mod_args):
+        """sum_r ci * A_r (dropout_r(cj) * X W_r) per destination type in one launch each.
+
+        Same arithmetic as HeteroGraphConv(aggregate='sum') over GCMCGraphConv (layers.py:98,
+        129,220-234); only the association of the final sum differs (all relations' edges are
+        added in one row sum instead of summing per-relation results).  Returns None when the
+        graph / inputs do not fit the fused form, and the caller falls back to the per-slice path.
+        """
+        if not hasattr(graph, "fused_relations"):
+            return None
+        plans = {}
+        for nt in graph.ntypes:
+            fr = graph.fused_relations(nt)
+            if fr is None:
+                return None
+            plans[nt] = fr
+        # dropout masks are drawn in canonical relation order, one (N_src, 1) draw per slice,
+        # exactly as the per-slice path does (layers.py:224)
+        drops, weights = {}, {}
+        for can in graph.canonical_etypes:
+            stype, etype, _ = can
+            conv = self.conv.mods[etype]
+            x = inputs.get(stype)
+            rel = graph[can]
+            ext_w = mod_args[etype][0]
+            if ext_w is not None and conv.weight is not None:
+                raise DGMIError("External weight provided but module also has its own weight parameter, "
+                                "please set weight=False.")
+            w = ext_w if ext_w is not None else conv.weight
+            if (x is None or w is None or conv.device is not None or x.dim() != 2 or x.shape[1] == 3
+                    or x.shape[0] != rel.number_of_src_nodes() or rel.srcdata["cj"].shape[0] != x.shape[0]):
+                return None
+            drops[can] = conv.dropout(rel.srcdata["cj"]).view(-1)
+            weights[can] = w
+        out = {}
+        for nt, (csr, cans) in plans.items():
+            x = inputs[cans[0][0]]
+            width = weights[cans[0]].shape[1]
+            if any(weights[c].shape != weights[cans[0]].shape for c in cans):
+                return None
+            pad = -width % 4  # keep rows 16-B aligned (341 -> 344), see GCMCGraphConv.forward
+            w_cat = torch.cat([F.pad(weights[c], (0, pad)) if pad else weights[c] for c in cans], dim=1)
+            feat = torch.matmul(x, w_cat).view(x.shape[0] * len(cans), width + pad)  # rows [u][r]
+            scale = torch.stack([drops[c] for c in cans], dim=1).reshape(-1)
+            y = ops.spmm_csr(csr, feat, src_scale=scale, dst_scale=graph[cans[0]].dstdata["ci"])
+            out[nt] = y if not pad else y[:, :width]
+        return out
 
 
 # -------------------------------------------------------------------------------------------

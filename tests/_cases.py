@@ -123,7 +123,7 @@ def build_enc(g, dev):
                              symm=True, device=dev).int()
 
 
-def case_gcmc_layer(dev, name):
+def case_gcmc_layer(dev, name, fuse=True):
     from dream_gnn_amd import layers as L
 
     g = load("gcmc_layer_" + name)
@@ -134,11 +134,14 @@ def case_gcmc_layer(dev, name):
                         share_user_item_param=bool(share))
     layer = load_sd(layer, g, dev)
     layer.train()
+    layer.fuse_relations = fuse
     enc = build_enc(g, dev)
     drug = T(g["drug"], dev).requires_grad_(True)
     dis = T(g["dis"], dev).requires_grad_(True)
     o_drug, o_dis = layer(enc, drug, dis)
     ((o_drug * T(g["d_drug"], dev)).sum() + (o_dis * T(g["d_dis"], dev)).sum()).backward()
+    fused = enc.__dict__.get("_fused", {})
+    assert (set(fused) == {"drug", "disease"} and all(v is not None for v in fused.values())) == fuse
     close(o_drug, g["o_drug"], 1e-5, "o_drug")
     close(o_dis, g["o_dis"], 1e-5, "o_dis")
     close(drug.grad, g["g_drug"], 1e-4, "g_drug")
@@ -238,3 +241,21 @@ def case_encgraph(dev, symm):
         assert dropped.number_of_edges(et) == int(g["drop_n_" + et])
     assert np.array_equal(dropped.nodes["drug"].data["ci"].cpu().numpy(), g["drop_drug_ci"])
     assert dropped.nodes["drug"].data["ci"].data_ptr() != hg.nodes["drug"].data["ci"].data_ptr()
+
+
+def case_similarity_graph(dev, name):
+    """(f4) device kNN-graph builder vs the reference's _create_similarity_graph output."""
+    from dream_gnn_amd import graph as G
+
+    g = load("simgraph_" + name)
+    adj = G.similarity_graph(T(g["sim"], dev), int(g["k"])).coalesce()
+    idx = adj.indices().cpu().numpy()
+    assert np.array_equal(idx[0], g["row"]) and np.array_equal(idx[1], g["col"])  # same edges, same order
+    assert np.array_equal(adj.values().cpu().numpy(), g["val"])  # float32(count / rowsum) exactly
+    # the cosine-feature variant agrees with the dense-similarity path on the same embeddings
+    rng = np.random.default_rng(1)
+    X = torch.from_numpy(rng.standard_normal((int(g["n"]), 16)).astype(np.float32)).to(dev)
+    xn = X / X.norm(dim=1, keepdim=True)
+    a = G.feature_similarity_graph(X, 3, block_rows=7).coalesce()
+    b = G.similarity_graph(xn @ xn.t(), 3).coalesce()
+    assert torch.equal(a.indices(), b.indices()) and torch.equal(a.values(), b.values())

@@ -22,9 +22,10 @@ def test_gcmc_graph_conv(dev, mode):
     C.case_gcmc_conv(dev, mode)
 
 
+@pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("name", ["shared_ini", "shared_noini", "unshared", "shareflag_dimdiff"])
-def test_gcmc_layer(dev, name):
-    C.case_gcmc_layer(dev, name)
+def test_gcmc_layer(dev, name, fuse):
+    C.case_gcmc_layer(dev, name, fuse)
 
 
 @pytest.mark.parametrize("name", ["both", "simonly"])
@@ -56,3 +57,8 @@ def test_native_library_is_what_runs(dev):
     assert os.path.realpath(_lib.LIB_PATH) in maps
     hip = {line.split()[-1] for line in maps.splitlines() if "libamdhip64" in line}
     assert len(hip) == 1, "two HIP runtimes loaded: %s" % hip
+
+
+@pytest.mark.parametrize("name", ["n30_k4", "n12_k20"])
+def test_similarity_graph_builder(dev, name):
+    C.case_similarity_graph(dev, name)

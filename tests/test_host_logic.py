@@ -32,9 +32,10 @@ def test_gcmc_graph_conv(mode):
     C.case_gcmc_conv(CPU, mode)
 
 
+@pytest.mark.parametrize("fuse", [True, False])
 @pytest.mark.parametrize("name", ["shared_ini", "shared_noini", "unshared", "shareflag_dimdiff"])
-def test_gcmc_layer(name):
-    C.case_gcmc_layer(CPU, name)
+def test_gcmc_layer(name, fuse):
+    C.case_gcmc_layer(CPU, name, fuse)
 
 
 @pytest.mark.parametrize("name", ["both", "simonly"])
@@ -162,3 +163,8 @@ def test_train_step_structure_on_cpu_backend():
     assert aug["dec_graph"] is batch["dec_graph"] and not torch.equal(aug["drug_feat"], batch["drug_feat"])
     auroc, aupr = H.evaluate(net, batch, labels)
     assert 0.0 <= auroc <= 1.0 and 0.0 <= aupr <= 1.0
+
+
+@pytest.mark.parametrize("name", ["n30_k4", "n12_k20"])
+def test_similarity_graph_builder(name):
+    C.case_similarity_graph(CPU, name)
