@@ -20,7 +20,8 @@ of every graph and all their in-edges), each local SpMM is followed by the all-g
 row block over RCCL, and the time is the max over ranks (see dream_gnn_amd/shard.py).
 
 The JSON line also carries `roofline` for the dominant kernel (the unweighted scaled F=128
-SpMM: algorithmic bytes / HIP-event time on the launch stream, against the 8 TB/s HBM peak) and
+SpMM — an XCD-local gather kernel plus its plane-reduce kernel: algorithmic bytes / HIP-event
+time of the pair on the launch stream, against the 8 TB/s HBM peak) and
 `cpu_baseline` (the OpenMP CPU oracle timed on this box's host cores on a bounded sample).
 """
 from __future__ import annotations
@@ -40,7 +41,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 F = 128
 BASE_DRUG, BASE_DIS, BASE_EDGES, KNN_K = 100_000, 50_000, 10_000_000, 64
-DOMINANT = "spmm_csr_vec4_kernel<32,false,true,true,true>"  # LPR=32 (F=128), unweighted, src+dst scale, planned
+# The GCMC product at F=128 on config 4's 25-51 MB feature tables runs as the XCD-local pair:
+# gather kernel (LPR=32, unweighted, src scale) + the 8-plane reduce (dst scale).  Its time is
+# taken with HIP events around the pair; rocprofv3's averages of the two kernels add up to it.
+DOMINANT = "spmm_sliced_vec4_kernel<32,false,true> + reduce_planes_kernel<true>"
 
 
 def algorithmic_bytes(nnz, n_rows, weighted, n_scales_src=0, n_scales_dst=0):
@@ -272,8 +276,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": committed_traffic(),
                 "launches": dom_n, "avg_launch_ms": dom_t / dom_n * 1e3,
                 "alg_bytes_per_launch": dom_b / dom_n,
-                "note": "algorithmic gather bytes; most per-edge row re-reads are served by L2 / Infinity Cache, "
-                        "so frac can exceed the HBM-only bound (see DESIGN.md)",
+                "note": "algorithmic gather bytes (plane scratch traffic of the XCD-local kernel not counted as "
+                        "useful); per-edge row re-reads are served by the XCD's L2 / Infinity Cache, so frac "
+                        "exceeds the HBM-only bound (see DESIGN.md)",
             },
             "kernels": per_op,
         }

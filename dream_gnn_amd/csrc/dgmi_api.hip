@@ -2,6 +2,7 @@
 // Host-side validation only; the kernels live in dgmi_spmm.hip / dgmi_csr.hip.
 #include <hip/hip_runtime.h>
 #include <limits.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "dgmi.h"
@@ -148,6 +149,76 @@ DGMI_API int dgmi_spmm_csr_planned_f32(const int32_t* indptr, const int32_t* ind
                    static_cast<const int32_t*>(plan), nnz, chunk, static_cast<float*>(partials),
                    (F + 3) / 4 * 4};
   return from_hip(dgmi::spmm_csr_f32(a, as_stream(stream)));
+}
+
+static int64_t slice_width_for(int64_t n_cols, int32_t n_slices) {
+  const int64_t w = (n_cols + n_slices - 1) / n_slices;
+  return w > 0 ? w : 1;
+}
+
+DGMI_API int dgmi_csr_sliced_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E, int64_t n_rows,
+                                          int64_t n_cols, int32_t n_slices, int32_t* segptr,
+                                          int32_t* indices, int32_t* eid, void* workspace,
+                                          size_t* workspace_bytes, dgmi_stream_t stream) {
+  if (E < 0 || n_rows < 0 || n_cols < 0 || n_slices < 1 || n_slices > 64 || workspace_bytes == nullptr)
+    return DGMI_ERR_INVALID_ARG;
+  if (E > INT32_MAX || n_cols >= INT32_MAX || n_rows * (int64_t)n_slices >= INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (workspace != nullptr) {
+    if (segptr == nullptr) return DGMI_ERR_INVALID_ARG;
+    if (E > 0 && (row == nullptr || col == nullptr || indices == nullptr || eid == nullptr))
+      return DGMI_ERR_INVALID_ARG;
+  }
+  const int64_t width = slice_width_for(n_cols, n_slices);
+  size_t need = 0;
+  if (dgmi::csr_sliced_from_coo_i32(row, col, E, n_rows, n_cols, n_slices, width, segptr, indices, eid, nullptr,
+                                    &need, as_stream(stream)) != hipSuccess)
+    return DGMI_ERR_LAUNCH;
+  if (workspace == nullptr) {
+    *workspace_bytes = need;
+    return DGMI_OK;
+  }
+  if (*workspace_bytes < need) return DGMI_ERR_WORKSPACE;
+  return from_hip(dgmi::csr_sliced_from_coo_i32(row, col, E, n_rows, n_cols, n_slices, width, segptr, indices,
+                                                eid, workspace, workspace_bytes, as_stream(stream)));
+}
+
+// Destination rows per launch pair: the n_slices partial planes of one chunk stay <= 32 MiB.
+static int64_t sliced_chunk_rows(int64_t n_dst, int32_t n_slices, int64_t F) {
+  const int64_t row_bytes = (int64_t)n_slices * ((F + 3) / 4 * 4) * (int64_t)sizeof(float);
+  int64_t rows = ((int64_t)4096 << 20) / (row_bytes > 0 ? row_bytes : 1);  // chunking off by default (measured slower)
+  rows = rows / 1024 * 1024;
+  if (rows < 1024) rows = 1024;
+  const char* env = getenv("DGMI_SLICED_CHUNK_ROWS");  // tuning aid
+  if (env != nullptr && atoll(env) > 0) rows = atoll(env);
+  return rows < n_dst ? rows : n_dst;
+}
+
+DGMI_API size_t dgmi_spmm_sliced_planes_bytes(int64_t n_dst, int32_t n_slices, int64_t F) {
+  if (n_dst < 0 || n_slices < 1 || F < 0) return 0;
+  const size_t b = (size_t)sliced_chunk_rows(n_dst, n_slices, F) * (size_t)n_slices *
+                   (size_t)((F + 3) / 4 * 4) * sizeof(float);
+  return b < 16 ? 16 : b;
+}
+
+DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices, const float* vals,
+                                  const float* X, int64_t ldx, const float* src_scale,
+                                  const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
+                                  int64_t n_src, int64_t F, int32_t n_slices, void* planes,
+                                  size_t planes_bytes, dgmi_stream_t stream) {
+  if (n_dst < 0 || n_src < 0 || F < 0 || n_slices < 1 || n_slices > 64) return DGMI_ERR_INVALID_ARG;
+  if (n_dst >= INT32_MAX || n_src >= INT32_MAX || F > INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (n_dst == 0 || F == 0) return DGMI_OK;
+  if (segptr == nullptr || Y == nullptr || planes == nullptr) return DGMI_ERR_INVALID_ARG;
+  if (X == nullptr && n_src > 0) return DGMI_ERR_INVALID_ARG;
+  if (ldx < F || ldy < F || F % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0) return DGMI_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(Y) & 15) ||
+      (reinterpret_cast<uintptr_t>(planes) & 15))
+    return DGMI_ERR_INVALID_ARG;
+  if (static_cast<const void*>(X) == static_cast<const void*>(Y)) return DGMI_ERR_INVALID_ARG;
+  if (planes_bytes < dgmi_spmm_sliced_planes_bytes(n_dst, n_slices, F)) return DGMI_ERR_WORKSPACE;
+  dgmi::SlicedArgs a{segptr, indices, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F, n_slices,
+                     static_cast<float*>(planes), F, sliced_chunk_rows(n_dst, n_slices, F)};
+  return from_hip(dgmi::spmm_sliced_f32(a, as_stream(stream)));
 }
 
 DGMI_API int dgmi_gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,

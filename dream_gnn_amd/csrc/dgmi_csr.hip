@@ -134,6 +134,83 @@ hipError_t csr_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// Source-sliced CSR for the XCD-local SpMM (dgmi_sliced.hip): the source id range is cut into
+// `n_slices` contiguous slices of `slice_width` ids and the edges are sorted, stably, by
+// key = slice(col) * n_rows + row.  segptr[s * n_rows + r] .. segptr[s * n_rows + r + 1] are the
+// edges of destination row r whose source lies in slice s: n_slices column-blocked CSRs stacked
+// slice-major, built by the same sort -> boundaries -> gather pipeline on the composite key.
+namespace {
+__global__ __launch_bounds__(kBlock) void slice_key_kernel(const int32_t* __restrict__ row,
+                                                           const int32_t* __restrict__ col, int64_t E,
+                                                           int32_t n_rows, int32_t n_cols,
+                                                           int32_t n_slices, int32_t slice_width,
+                                                           int32_t* __restrict__ key,
+                                                           int32_t* __restrict__ tmp_eid,
+                                                           int32_t* __restrict__ flag) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  bool bad = false;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += stride) {
+    tmp_eid[e] = (int32_t)e;
+    int32_t r = row[e], c = col[e];
+    const bool oob = (r < 0) | (r >= n_rows) | (c < 0) | (c >= n_cols);
+    bad |= oob;
+    if (oob) r = c = 0;  // keep the key inside [0, n_slices * n_rows); the flag reports it
+    int32_t sl = c / slice_width;
+    if (sl >= n_slices) sl = n_slices - 1;
+    key[e] = sl * n_rows + r;
+  }
+  if (bad) *flag = 1;
+}
+}  // namespace
+
+hipError_t csr_sliced_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E, int64_t n_rows,
+                                   int64_t n_cols, int64_t n_slices, int64_t slice_width,
+                                   int32_t* segptr, int32_t* indices, int32_t* eid, void* workspace,
+                                   size_t* workspace_bytes, hipStream_t s) {
+  const int64_t n_keys = n_rows * n_slices;
+  const int end_bit = bits_for(n_keys);
+  size_t sort_bytes = 0;
+  if (E > 0) {
+    hipError_t err = rocprim::radix_sort_pairs(
+        nullptr, sort_bytes, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+        static_cast<const int32_t*>(nullptr), eid, (size_t)E, 0u, (unsigned)end_bit, s);
+    if (err != hipSuccess) return err;
+  }
+  const size_t off_flag = 0;
+  const size_t off_keys_in = 256;
+  const size_t off_keys = off_keys_in + align_up((size_t)E * 4, 256);
+  const size_t off_iota = off_keys + align_up((size_t)E * 4, 256);
+  const size_t off_sort = off_iota + align_up((size_t)E * 4, 256);
+  const size_t total = off_sort + align_up(sort_bytes, 256);
+  if (workspace == nullptr) {
+    *workspace_bytes = total;
+    return hipSuccess;
+  }
+  if (*workspace_bytes < total) return hipErrorInvalidValue;
+  char* ws = static_cast<char*>(workspace);
+  int32_t* flag = reinterpret_cast<int32_t*>(ws + off_flag);
+  int32_t* keys_in = reinterpret_cast<int32_t*>(ws + off_keys_in);
+  int32_t* keys_out = reinterpret_cast<int32_t*>(ws + off_keys);
+  int32_t* tmp_eid = reinterpret_cast<int32_t*>(ws + off_iota);
+  void* sort_tmp = ws + off_sort;
+  hipError_t err = hipMemsetAsync(flag, 0, 256, s);
+  if (err != hipSuccess) return err;
+  if (E > 0) {
+    hipLaunchKernelGGL(slice_key_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, row, col, E,
+                       (int32_t)n_rows, (int32_t)n_cols, (int32_t)n_slices, (int32_t)slice_width,
+                       keys_in, tmp_eid, flag);
+    err = rocprim::radix_sort_pairs(sort_tmp, sort_bytes, reinterpret_cast<const uint32_t*>(keys_in),
+                                    reinterpret_cast<uint32_t*>(keys_out),
+                                    static_cast<const int32_t*>(tmp_eid), eid, (size_t)E, 0u,
+                                    (unsigned)end_bit, s);
+    if (err != hipSuccess) return err;
+  }
+  hipLaunchKernelGGL(boundaries_gather_kernel, dim3(grid_for(E + 1)), dim3(kBlock), 0, s, keys_out,
+                     eid, col, E, (int32_t)n_keys, segptr, indices);
+  return hipGetLastError();
+}
+
 hipError_t gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,
                       hipStream_t s) {
   if (n == 0) return hipSuccess;

@@ -68,6 +68,30 @@ hipError_t csr_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
                             int32_t* eid, void* workspace, size_t* workspace_bytes,
                             hipStream_t s);
 
+// Source-sliced CSR (dgmi_csr.hip) and the XCD-local SpMM over it (dgmi_sliced.hip).
+hipError_t csr_sliced_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E, int64_t n_rows,
+                                   int64_t n_cols, int64_t n_slices, int64_t slice_width,
+                                   int32_t* segptr, int32_t* indices, int32_t* eid, void* workspace,
+                                   size_t* workspace_bytes, hipStream_t s);
+
+struct SlicedArgs {
+  const int32_t* segptr;   // n_slices * n_dst + 1
+  const int32_t* indices;
+  const float* vals;       // nullable, sliced order
+  const float* X;
+  int64_t ldx;
+  const float* src_scale;  // nullable
+  const float* dst_scale;  // nullable
+  float* Y;
+  int64_t ldy;
+  int64_t n_dst, n_src, F;
+  int64_t n_slices;
+  float* planes;           // n_slices * min(n_dst, chunk_rows) * ldp floats of scratch
+  int64_t ldp;
+  int64_t chunk_rows;      // destination rows per launch pair (planes stay Infinity-Cache resident)
+};
+hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s);
+
 // out[e] = cat(A[src[e]], B[dst[e]])   (dgmi_edge.hip)
 hipError_t gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
                              int64_t lda, int64_t Fa, const float* B, int64_t ldb, int64_t Fb,

@@ -50,6 +50,7 @@ class RelationGraph:
         self.srcdata, self.dstdata = srcdata, dstdata
         self._csr: Optional[ops.CSRGraph] = None
         self.trusted = False  # ids already validated (edge lists derived from a checked graph)
+        self.regular_hint = None  # degree regularity inherited from the parent graph (edge dropout)
 
     # -- the DGL surface the reference's layer code uses ---------------------------------
     def number_of_src_nodes(self) -> int:
@@ -89,7 +90,8 @@ class RelationGraph:
     @property
     def csr(self) -> ops.CSRGraph:
         if self._csr is None:
-            self._csr = ops.CSRGraph(self.dst, self.src, self.n_dst, self.n_src, check_range=not self.trusted)
+            self._csr = ops.CSRGraph(self.dst, self.src, self.n_dst, self.n_src, check_range=not self.trusted,
+                                     regular=self.regular_hint)
         return self._csr
 
 
@@ -336,6 +338,8 @@ def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
     out = HeteroGraph(data, {nt: graph.number_of_nodes(nt) for nt in graph.ntypes})
     for can in out.canonical_etypes:
         out[can].trusted = True  # a subset of an existing graph's edges: no range re-check, no host sync
+        parent = graph[can]._csr
+        out[can].regular_hint = parent.regular if parent is not None else None  # dropping edges keeps it regular
     for nt in graph.ntypes:
         for k, v in graph.nodes[nt].data.items():
             out.nodes[nt].data[k] = v.clone()

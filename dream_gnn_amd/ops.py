@@ -215,6 +215,72 @@ def spmm_csr_raw(indptr, indices, vals, X, src_scale=None, dst_scale=None, out=N
     return _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx)
 
 
+def _sliced_ok(X, out) -> bool:
+    """16-B alignment requirements of ``dgmi_spmm_sliced_f32``."""
+    if X.dtype != torch.float32 or X.stride(1) != 1 or X.stride(0) % 4 != 0 or X.data_ptr() % 16 != 0:
+        return False
+    return out is None or (out.is_contiguous() and out.data_ptr() % 16 == 0)
+
+
+class SlicedCSR:
+    """Source-sliced CSR for the XCD-local SpMM (``dgmi_csr_sliced_from_coo_i32``): edges sorted
+    by (slice(src), row); ``segptr`` has ``n_slices * n_dst + 1`` entries."""
+
+    N_SLICES = 8  # one slice of X per XCD
+
+    def __init__(self, dst, src, n_dst, n_src, vals=None, n_slices: int = N_SLICES):
+        dev = _require_device(dst, src, vals)
+        self.n_dst, self.n_src, self.n_slices = int(n_dst), int(n_src), int(n_slices)
+        E = dst.shape[0]
+        with _guard(dev):
+            self.segptr = torch.empty(self.n_slices * self.n_dst + 1, dtype=torch.int32, device=dev)
+            self.indices = torch.empty(E, dtype=torch.int32, device=dev)
+            self.eid = torch.empty(E, dtype=torch.int32, device=dev)
+            need = ctypes.c_size_t(0)
+            _lib.check(_L.dgmi_csr_sliced_from_coo_i32(_ptr(dst), _ptr(src), E, self.n_dst, self.n_src, self.n_slices,
+                                                       None, None, None, None, ctypes.byref(need), None),
+                       "dgmi_csr_sliced_from_coo_i32(size query)")
+            ws = torch.empty(max(int(need.value), 256), dtype=torch.uint8, device=dev)
+            have = ctypes.c_size_t(ws.numel())
+            _lib.check(_L.dgmi_csr_sliced_from_coo_i32(_ptr(dst), _ptr(src), E, self.n_dst, self.n_src, self.n_slices,
+                                                       _ptr(self.segptr), _ptr(self.indices), _ptr(self.eid),
+                                                       _ptr(ws), ctypes.byref(have), _stream(dev)),
+                       "dgmi_csr_sliced_from_coo_i32")
+        self.vals = None if vals is None else gather_f32(vals, self.eid)
+        self._pbytes = {}
+
+    def spmm(self, X, src_scale=None, dst_scale=None, out=None):
+        dev = self.segptr.device
+        if not X.is_cuda or X.device != dev:
+            _require_device(self.segptr, X)
+        X, n_x, F, ldx = _prep_dense(X)
+        if n_x != self.n_src:
+            raise RuntimeError("X has %d rows, the graph has %d source nodes" % (n_x, self.n_src))
+        src_scale = _prep_scale(src_scale, self.n_src, "src_scale")
+        dst_scale = _prep_scale(dst_scale, self.n_dst, "dst_scale")
+        if out is None:
+            out = torch.empty((self.n_dst, F), dtype=torch.float32, device=dev)
+        elif out.dtype != torch.float32 or tuple(out.shape) != (self.n_dst, F) or not out.is_contiguous():
+            raise RuntimeError("out must be a contiguous float32 (%d, %d) tensor" % (self.n_dst, F))
+        with _guard(dev):
+            pbytes = self._pbytes.get(F)
+            if pbytes is None:
+                pbytes = self._pbytes[F] = int(_L.dgmi_spmm_sliced_planes_bytes(self.n_dst, self.n_slices, F))
+            planes = torch.empty(pbytes, dtype=torch.uint8, device=dev)
+            _lib.check(_L.dgmi_spmm_sliced_f32(self.segptr.data_ptr(), self.indices.data_ptr(), _ptr(self.vals),
+                                               X.data_ptr(), ldx, _ptr(src_scale), _ptr(dst_scale), out.data_ptr(),
+                                               F, self.n_dst, self.n_src, F, self.n_slices, planes.data_ptr(), pbytes,
+                                               _stream(dev)), "dgmi_spmm_sliced_f32")
+        return out
+
+
+# XCD-local path is used when the gather table is a few L2s large (8 XCDs x 4 MiB): below, X is
+# L2/IC-hot anyway; above ~96 MiB a 1/8 slice no longer fits an L2 and the plane traffic is pure cost.
+SLICED_MIN_TABLE_BYTES = 12 << 20
+SLICED_MAX_TABLE_BYTES = 96 << 20
+SLICED_MIN_AVG_DEGREE = 32
+
+
 class CSRGraph:
     """A relation slice / sparse adjacency in the layout the kernels read.
 
@@ -227,7 +293,8 @@ class CSRGraph:
     """
 
     def __init__(self, dst: torch.Tensor, src: torch.Tensor, n_dst: int, n_src: int,
-                 vals: Optional[torch.Tensor] = None, check_range: bool = True, planned: bool = True):
+                 vals: Optional[torch.Tensor] = None, check_range: bool = True, planned: bool = True,
+                 regular: Optional[bool] = None):
         _require_device(dst, src, vals)
         self.n_dst, self.n_src = int(n_dst), int(n_src)
         self._dst = dst.to(torch.int32).contiguous()
@@ -236,11 +303,20 @@ class CSRGraph:
         if self._coo_vals is not None and self._coo_vals.shape[0] != self._dst.shape[0]:
             raise RuntimeError("vals/edge-list length mismatch")
         self.indptr, self.indices, self.eid = csr_from_coo(self._dst, self._src, self.n_dst, self.n_src,
-                                                           check_range=check_range)
+                                                           check_range=False)
         self.vals = None if self._coo_vals is None else gather_f32(self._coo_vals, self.eid)
         self._planned = planned
         self.plan = build_plan(self.indptr, self.nnz) if planned else None
         self._t = None
+        self._sliced = None      # lazily built SlicedCSR of the forward direction
+        self._sliced_t = None
+        # `regular`: no destination row is extremely long, so the XCD-local kernel (which walks a
+        # (row, slice) segment sequentially) is safe to use.  Known after the one readback below;
+        # unknown (False) for unchecked builds unless the caller vouches for it.
+        self.regular = bool(regular) if regular is not None else False
+        self.regular_t = None
+        if check_range:
+            self._validate()
 
     @property
     def nnz(self) -> int:
@@ -249,6 +325,30 @@ class CSRGraph:
     @property
     def device(self):
         return self.indptr.device
+
+    @staticmethod
+    def _is_regular(max_deg: int, nnz: int, n_rows: int) -> bool:
+        return max_deg <= max(256, 8 * (nnz // max(n_rows, 1)))
+
+    def _validate(self):
+        """One host sync: id range check (row ids via the sort's key range, column ids here) and
+        the maximum in-degree."""
+        if self.nnz == 0:
+            self.regular = True
+            return
+        stats = torch.stack([self._dst.min(), self._dst.max(), self._src.min(), self._src.max(),
+                             (self.indptr[1:] - self.indptr[:-1]).max()]).tolist()
+        dlo, dhi, slo, shi, max_deg = (int(v) for v in stats)
+        if dlo < 0 or dhi >= self.n_dst:
+            raise RuntimeError("destination id out of range [0, %d): min %d max %d" % (self.n_dst, dlo, dhi))
+        if slo < 0 or shi >= self.n_src:
+            raise RuntimeError("source id out of range [0, %d): min %d max %d" % (self.n_src, slo, shi))
+        self.regular = self._is_regular(max_deg, self.nnz, self.n_dst)
+
+    def _use_sliced(self, F: int, n_rows: int, n_cols: int, regular: bool) -> bool:
+        table = n_cols * F * 4
+        return (regular and F % 4 == 0 and SLICED_MIN_TABLE_BYTES <= table <= SLICED_MAX_TABLE_BYTES
+                and self.nnz >= SLICED_MIN_AVG_DEGREE * n_rows and n_rows * SlicedCSR.N_SLICES < 2 ** 31 - 1)
 
     def transposed(self):
         """(indptr_t, indices_t, vals_t, plan_t): CSR of the reversed edges, rows = source nodes."""
@@ -275,13 +375,26 @@ class CSRGraph:
         return _launch_spmm(dev, indptr, indices, vals, X, col_scale, row_scale, out, plan, n_rows, n_cols, F, ldx)
 
     def spmm(self, X, src_scale=None, dst_scale=None, out=None):
-        """``diag(dst_scale) A diag(src_scale) X`` (no autograd)."""
+        """``diag(dst_scale) A diag(src_scale) X`` (no autograd).  Picks the XCD-local sliced
+        kernel when the feature table is a few L2s large and the graph is regular, else the
+        planned kernel."""
+        if X.dim() == 2 and self._use_sliced(X.shape[1], self.n_dst, self.n_src, self.regular) and _sliced_ok(X, out):
+            if self._sliced is None:
+                self._sliced = SlicedCSR(self._dst, self._src, self.n_dst, self.n_src, vals=self._coo_vals)
+            return self._sliced.spmm(X, src_scale, dst_scale, out)
         return self._run(self.indptr, self.indices, self.vals, self.plan, self.n_dst, self.n_src, X,
                          src_scale, dst_scale, out)
 
     def spmm_t(self, dY, src_scale=None, dst_scale=None, out=None):
         """``diag(src_scale) A^T diag(dst_scale) dY`` — the backward of :meth:`spmm`."""
         indptr_t, indices_t, vals_t, plan_t = self.transposed()
+        if self.regular_t is None:  # one-time readback of the reversed graph's maximum degree
+            max_deg = int((indptr_t[1:] - indptr_t[:-1]).max()) if self.nnz else 0
+            self.regular_t = self.regular and self._is_regular(max_deg, self.nnz, self.n_src)
+        if dY.dim() == 2 and self._use_sliced(dY.shape[1], self.n_src, self.n_dst, self.regular_t) and _sliced_ok(dY, out):
+            if self._sliced_t is None:
+                self._sliced_t = SlicedCSR(self._src, self._dst, self.n_src, self.n_dst, vals=self._coo_vals)
+            return self._sliced_t.spmm(dY, dst_scale, src_scale, out)
         return self._run(indptr_t, indices_t, vals_t, plan_t, self.n_src, self.n_dst, dY, dst_scale, src_scale, out)
 
 

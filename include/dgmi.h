@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 4
+#define DGMI_ABI_VERSION 5
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -158,6 +158,35 @@ DGMI_API int dgmi_spmm_csr_planned_f32(const int32_t* indptr, const int32_t* ind
  */
 DGMI_API int dgmi_gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,
                     dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
+ * XCD-local SpMM: the same product over a source-sliced CSR.
+ *
+ * MI355X's 8 XCDs each have a private 4 MiB L2 and workgroups are dealt round-robin over
+ * them.  When the feature table X is a few L2s large (n_src * 4F up to ~64 MB) the gather is
+ * 2-3x faster if every workgroup of XCD s only touches slice s of X.  The sliced CSR stores
+ * the edges sorted by (slice(src), row): segptr[s * n_rows + r] .. [s * n_rows + r + 1] are row
+ * r's edges with source in [s * slice_width, (s+1) * slice_width).  `eid` maps sliced positions
+ * to the caller's edge order (for per-edge values).  The in-row summation order is slice by
+ * slice, input order inside a slice: deterministic, but not the plain CSR's order.
+ *
+ *   dgmi_csr_sliced_from_coo_i32   workspace protocol and error flag as dgmi_csr_from_coo_i32
+ *                                  (n_cols is required here; n_slices in [1, 64])
+ *   planes = device scratch of dgmi_spmm_sliced_planes_bytes(n_dst, n_slices, F) bytes
+ *   dgmi_spmm_sliced_f32           requires F % 4 == 0, ldx % 4 == 0, ldy % 4 == 0 and 16-B
+ *                                  aligned X / Y / planes (returns DGMI_ERR_INVALID_ARG otherwise)
+ */
+DGMI_API int dgmi_csr_sliced_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
+                                          int64_t n_rows, int64_t n_cols, int32_t n_slices,
+                                          int32_t* segptr, int32_t* indices, int32_t* eid,
+                                          void* workspace, size_t* workspace_bytes,
+                                          dgmi_stream_t stream);
+DGMI_API size_t dgmi_spmm_sliced_planes_bytes(int64_t n_dst, int32_t n_slices, int64_t F);
+DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices, const float* vals,
+                                  const float* X, int64_t ldx, const float* src_scale,
+                                  const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
+                                  int64_t n_src, int64_t F, int32_t n_slices, void* planes,
+                                  size_t planes_bytes, dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
  * (f2) Per-edge gather-concat: out[e, 0:Fa] = A[src[e], :], out[e, Fa:Fa+Fb] = B[dst[e], :].

@@ -102,6 +102,20 @@ def csr_from_coo(row, col, n_rows):
     return indptr, indices, eid
 
 
+def csr_sliced_from_coo(row, col, n_rows, n_cols, n_slices):
+    """Source-sliced CSR (the XCD-local kernel's layout): stable sort by
+    ``slice(col) * n_rows + row`` with ``slice = col // ceil(n_cols / n_slices)``.
+    Returns (segptr[n_slices*n_rows+1], indices, eid)."""
+    row = np.asarray(row, np.int64)
+    col = np.asarray(col, np.int64)
+    width = max(1, -(-int(n_cols) // int(n_slices)))
+    key = np.minimum(col // width, n_slices - 1) * n_rows + row
+    order = np.argsort(key, kind="stable")
+    segptr = np.zeros(n_slices * n_rows + 1, np.int64)
+    np.add.at(segptr, key + 1, 1)
+    return np.cumsum(segptr).astype(np.int32), col[order].astype(np.int32), order.astype(np.int32)
+
+
 def spmm_csr(indptr, indices, vals, X, src_scale=None, dst_scale=None, threads=1, acc="f32", validate=True):
     """``Y = diag(dst_scale) A diag(src_scale) X`` over a CSR; ``vals=None`` is
     ``update_all(copy_u, sum)`` (layers.py:229-232), else ``th.spmm`` (layers.py:312).

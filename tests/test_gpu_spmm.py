@@ -224,3 +224,83 @@ def test_gather_concat_empty_and_range_check(dev):
     with pytest.raises(RuntimeError):
         ops.EdgePairs(torch.tensor([0, 9], dtype=torch.int32, device=dev),
                       torch.tensor([0, 0], dtype=torch.int32, device=dev), 3, 3)
+
+
+@pytest.mark.parametrize("F", [4, 32, 64, 128, 256, 344])
+@pytest.mark.parametrize("mode", ["copy_u", "all"])
+@pytest.mark.parametrize("n_slices", [8, 3])
+def test_xcd_sliced_spmm_vs_oracle(oracle, dev, F, mode, n_slices):
+    """The XCD-local path: sliced CSR layout bit-exact vs its numpy restatement, product within
+    1e-5 of the f64 oracle (its in-row order is slice by slice, so it is compared against f64,
+    not against the plain-CSR fp32 order)."""
+    from dream_gnn_amd import ops
+
+    rng = np.random.default_rng(F + n_slices)
+    n_dst, n_src, E = 203, 157, 7000
+    dst, src = _rand_graph(rng, n_dst, n_src, E)
+    X = rng.standard_normal((n_src, F)).astype(np.float32)
+    vals = rng.standard_normal(E).astype(np.float32) if mode == "all" else None
+    ss = rng.uniform(0.1, 1.0, n_src).astype(np.float32) if mode == "all" else None
+    ds = rng.uniform(0.1, 1.0, n_dst).astype(np.float32) if mode == "all" else None
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    sl = ops.SlicedCSR(t(dst), t(src), n_dst, n_src, vals=t(vals), n_slices=n_slices)
+    segptr, indices, eid = oracle.csr_sliced_from_coo(dst, src, n_dst, n_src, n_slices)
+    assert np.array_equal(sl.segptr.cpu().numpy(), segptr)
+    assert np.array_equal(sl.indices.cpu().numpy(), indices)
+    assert np.array_equal(sl.eid.cpu().numpy(), eid)
+    y = sl.spmm(t(X), t(ss), t(ds)).cpu().numpy()
+    ip, ix, e0 = oracle.csr_from_coo(dst, src, n_dst)
+    v0 = None if vals is None else vals[e0]
+    y64 = oracle.spmm_csr(ip, ix, v0, X, ss, ds, acc="f64")
+    yabs = oracle.spmm_csr(ip, ix, v0, X, ss, ds, acc="abs")
+    assert np.all(np.abs(y - y64) <= RTOL * yabs + 1e-30)
+    assert np.abs(y - y64).max() <= RTOL * np.abs(y64).max()
+    assert np.all(y[np.diff(ip) == 0] == 0)
+    assert np.array_equal(y, sl.spmm(t(X), t(ss), t(ds)).cpu().numpy())  # reproducible
+
+
+def test_xcd_sliced_edge_cases(oracle, dev):
+    from dream_gnn_amd import ops
+
+    z = torch.zeros(0, dtype=torch.int32, device=dev)
+    sl = ops.SlicedCSR(z, z, 5, 3)  # no edges, fewer sources than slices
+    assert torch.equal(sl.spmm(torch.randn(3, 8, device=dev)), torch.zeros(5, 8, device=dev))
+    rng = np.random.default_rng(1)
+    dst = np.concatenate([np.full(5000, 2, np.int32), rng.integers(0, 9, 300, dtype=np.int32)])  # one long row
+    src = rng.integers(0, 5, dst.size, dtype=np.int32)
+    X = rng.standard_normal((5, 128)).astype(np.float32)
+    sl = ops.SlicedCSR(torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev), 9, 5)
+    ip, ix, _ = oracle.csr_from_coo(dst, src, 9)
+    y64 = oracle.spmm_csr(ip, ix, None, X, acc="f64")
+    y = sl.spmm(torch.from_numpy(X).to(dev)).cpu().numpy()
+    assert np.abs(y - y64).max() <= 1e-5 * np.abs(y64).max()
+
+
+def test_csrgraph_picks_sliced_only_when_profitable(dev):
+    from dream_gnn_amd import ops
+
+    gen = torch.Generator(device=dev).manual_seed(0)
+    n_dst, n_src, E = 20_000, 40_000, 2_000_000  # table 40k x 128 x 4 = 20 MB, avg degree 100
+    dst = torch.randint(0, n_dst, (E,), generator=gen, device=dev, dtype=torch.int32)
+    src = torch.randint(0, n_src, (E,), generator=gen, device=dev, dtype=torch.int32)
+    g = ops.CSRGraph(dst, src, n_dst, n_src)
+    assert g.regular
+    X = torch.randn(n_src, 128, device=dev)
+    y = g.spmm(X)
+    assert g._sliced is not None  # XCD-local path taken
+    y_plain = ops.spmm_csr_raw(g.indptr, g.indices, None, X)
+    assert float((y - y_plain).abs().max()) <= 1e-5 * float(y_plain.abs().max())
+    W = torch.randn(n_dst, 128, device=dev)
+    dx = g.spmm_t(W)
+    it, ix, _, _ = g.transposed()
+    dx_plain = ops.spmm_csr_raw(it, ix, None, W)
+    assert float((dx - dx_plain).abs().max()) <= 1e-5 * float(dx_plain.abs().max())
+    g.spmm(torch.randn(n_src, 16, device=dev))  # 2.5 MB table: stays on the planned kernel
+    small = ops.CSRGraph(dst[:1000] % 50, src[:1000] % 60, 50, 60)
+    small.spmm(torch.randn(60, 128, device=dev))
+    assert small._sliced is None
+    # a power-law graph is not "regular": never sliced
+    p = 1.0 / torch.arange(1, n_dst + 1, device=dev, dtype=torch.float64) ** 1.2
+    skew = ops.CSRGraph(torch.multinomial(p / p.sum(), E, replacement=True, generator=gen).to(torch.int32), src, n_dst, n_src)
+    skew.spmm(X)
+    assert not skew.regular and skew._sliced is None

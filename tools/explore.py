@@ -93,3 +93,34 @@ if "decoder" in which:
         da = torch.zeros(nd, 128, device=dev); db = torch.zeros(ns, 128, device=dev)
         ms_bt = timeit(lambda: (da.index_add_(0, s.long(), dO[:, :128]), db.index_add_(0, d.long(), dO[:, 128:])))
         print(f"decoder gather-concat {tag} E={E}: hip {ms*1e3:.1f} us ({E*256*4*2/ms/1e6:.0f} GB/s r+w) vs torch index_select+cat {ms_t*1e3:.1f} us | bwd hip {ms_b*1e3:.1f} us vs torch index_add {ms_bt*1e3:.1f} us", flush=True)
+if "xcdlocal" in which:
+    # Upper bound for an XCD-sliced gather: rows whose block lands on XCD s (block = row/4, XCD = block % 8)
+    # only reference sources inside slice s of X. Same kernel, same bytes; only L2 locality changes.
+    for n_src in (50_000, 100_000, 400_000):
+        n_dst, E = 50_000, 10_000_000
+        dst = torch.randint(0, n_dst, (E,), generator=gen, device=dev, dtype=torch.int32)
+        w = n_src // 8
+        off = torch.randint(0, w, (E,), generator=gen, device=dev, dtype=torch.int32)
+        src_local = ((dst // 4) % 8) * w + off
+        src_rand = torch.randint(0, n_src, (E,), generator=gen, device=dev, dtype=torch.int32)
+        X = torch.randn(n_src, 128, device=dev)
+        for nm, src in (("xcd-local", src_local), ("uniform", src_rand)):
+            g = ops.CSRGraph(dst, src, n_dst, n_src)
+            report(f"{nm} sources, table {n_src*512/1e6:.0f} MB (slice {n_src*64/1e6:.1f} MB)", g, X, 128)
+if "sliced" in which:
+    for n_dst, n_src, E, weighted in ((50_000, 100_000, 10_000_000, False), (100_000, 50_000, 10_000_000, False), (100_000, 100_000, 12_900_000, True)):
+        dst = torch.randint(0, n_dst, (E,), generator=gen, device=dev, dtype=torch.int32)
+        src = torch.randint(0, n_src, (E,), generator=gen, device=dev, dtype=torch.int32)
+        vals = torch.rand(E, generator=gen, device=dev) if weighted else None
+        g = ops.CSRGraph(dst, src, n_dst, n_src, vals=vals)
+        X = torch.randn(n_src, 128, device=dev)
+        ss = torch.rand(n_src, device=dev); ds = torch.rand(n_dst, device=dev)
+        y0 = g.spmm(X, ss, ds)
+        for S in (4, 8, 16):
+            sl = ops.SlicedCSR(dst, src, n_dst, n_src, vals=vals, n_slices=S)
+            y1 = sl.spmm(X, ss, ds)
+            err = float((y1 - y0).abs().max() / y0.abs().max())
+            Y = torch.empty_like(y0)
+            ms = timeit(lambda: sl.spmm(X, ss, ds, out=Y))
+            ms0 = timeit(lambda: g.spmm(X, ss, ds, out=Y))
+            print(f"sliced S={S}: {n_src}->{n_dst} E={E} w={weighted}: sliced {ms*1e3:.1f} us vs planned {ms0*1e3:.1f} us  ({E/ms/1e6:.1f} Gedge/s) rel diff {err:.2e}", flush=True)

@@ -55,7 +55,13 @@ with open(os.path.join(out, tag + "_pmc_summary.csv"), "w", newline="") as fh:
     wr.writeheader()
     wr.writerows(rows)
 
-dom = [r for r in rows if "spmm_csr_vec4_kernel<32, false, true, true" in r["kernel"]]
+main = [r for r in rows if r["kernel"].startswith("spmm_sliced_vec4_kernel<32, false, true>")]
+red = [r for r in rows if r["kernel"].startswith("reduce_planes_kernel<true>")]
+dom = None
+if main and red:
+    dom = [{"kernel": main[0]["kernel"] + " + " + red[0]["kernel"],
+            "hbm_bytes_corrected_avg": main[0]["hbm_bytes_corrected_avg"] + red[0]["hbm_bytes_corrected_avg"],
+            "L2_hit_rate": main[0]["L2_hit_rate"]}]
 if dom:
     json.dump({"kernel": dom[0]["kernel"], "hbm_bytes_per_launch": dom[0]["hbm_bytes_corrected_avg"],
                "source": "profiles/%s_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
