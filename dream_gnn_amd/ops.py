@@ -275,10 +275,13 @@ class SlicedCSR:
 
 
 # XCD-local path is used when the gather table is a few L2s large (8 XCDs x 4 MiB): below, X is
-# L2/IC-hot anyway; above ~96 MiB a 1/8 slice no longer fits an L2 and the plane traffic is pure cost.
-SLICED_MIN_TABLE_BYTES = 12 << 20
-SLICED_MAX_TABLE_BYTES = 96 << 20
-SLICED_MIN_AVG_DEGREE = 32
+# L2-hot anyway; far above, a 1/8 slice no longer fits an L2 and the plane traffic is pure cost.
+# Measured on MI355X (tools/explore.py slicedcap, 10 M edges, F=128): sliced/planned time ratio
+# 1.0 at a 6 MB table, 1.9-2.4x at 13-51 MB, 1.2x at 102 MB, 1.0 at 205 MB; 1.55x at average
+# degree 100, 0.72x at 25 (a (row, slice) segment of 3 edges is all overhead).
+SLICED_MIN_TABLE_BYTES = 10 << 20
+SLICED_MAX_TABLE_BYTES = 160 << 20
+SLICED_MIN_AVG_DEGREE = 64
 
 
 class CSRGraph:

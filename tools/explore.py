@@ -124,3 +124,29 @@ if "sliced" in which:
             ms = timeit(lambda: sl.spmm(X, ss, ds, out=Y))
             ms0 = timeit(lambda: g.spmm(X, ss, ds, out=Y))
             print(f"sliced S={S}: {n_src}->{n_dst} E={E} w={weighted}: sliced {ms*1e3:.1f} us vs planned {ms0*1e3:.1f} us  ({E/ms/1e6:.1f} Gedge/s) rel diff {err:.2e}", flush=True)
+if "slicedcap" in which:
+    n_dst, E = 50_000, 10_000_000
+    for n_src in (12_500, 25_000, 50_000, 100_000, 150_000, 200_000, 300_000, 400_000, 800_000):
+        dst = torch.randint(0, n_dst, (E,), generator=gen, device=dev, dtype=torch.int32)
+        src = torch.randint(0, n_src, (E,), generator=gen, device=dev, dtype=torch.int32)
+        g = ops.CSRGraph(dst, src, n_dst, n_src)
+        X = torch.randn(n_src, 128, device=dev)
+        Y = torch.empty(n_dst, 128, device=dev)
+        sl = ops.SlicedCSR(dst, src, n_dst, n_src)
+        ms_s = timeit(lambda: sl.spmm(X, out=Y))
+        ms_p = timeit(lambda: ops.spmm_csr_raw(g.indptr, g.indices, None, X, out=Y, plan=g.plan))
+        print(f"table {n_src*512/1e6:6.1f} MB: sliced {ms_s*1e3:6.1f} us  planned {ms_p*1e3:6.1f} us  ratio {ms_p/ms_s:.2f}", flush=True)
+        del g, sl, X
+    # average degree sweep at the 51 MB table
+    n_src = 100_000
+    X = torch.randn(n_src, 128, device=dev)
+    for n_dst in (25_000, 100_000, 400_000, 1_000_000):
+        dst = torch.randint(0, n_dst, (E,), generator=gen, device=dev, dtype=torch.int32)
+        src = torch.randint(0, n_src, (E,), generator=gen, device=dev, dtype=torch.int32)
+        g = ops.CSRGraph(dst, src, n_dst, n_src)
+        Y = torch.empty(n_dst, 128, device=dev)
+        sl = ops.SlicedCSR(dst, src, n_dst, n_src)
+        ms_s = timeit(lambda: sl.spmm(X, out=Y))
+        ms_p = timeit(lambda: ops.spmm_csr_raw(g.indptr, g.indices, None, X, out=Y, plan=g.plan))
+        print(f"avg degree {E/n_dst:6.1f}: sliced {ms_s*1e3:6.1f} us  planned {ms_p*1e3:6.1f} us  ratio {ms_p/ms_s:.2f}", flush=True)
+        del g, sl
