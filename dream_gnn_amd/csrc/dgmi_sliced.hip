@@ -106,6 +106,25 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
         if (WEIGHTED) w[u] = __shfl(my_w, gbase + e, kWave);
         v[u] = ld4(Xc + (int64_t)idx * ldx);
       }
+      // fast path (group-uniform): all 8 edges belong to the current row -> balanced tree, no
+      // per-edge boundary tests
+      if (base + j + kUnroll <= next_b) {
+        if (WEIGHTED) {
+#pragma unroll
+          for (int u = 0; u < kUnroll; ++u) {
+            v[u].x *= w[u];
+            v[u].y *= w[u];
+            v[u].z *= w[u];
+            v[u].w *= w[u];
+          }
+        }
+        tree_sum(v, kUnroll);
+        acc.x += v[0].x;
+        acc.y += v[0].y;
+        acc.z += v[0].z;
+        acc.w += v[0].w;
+        continue;
+      }
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         const int p = base + j + u;
