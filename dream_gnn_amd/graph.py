@@ -50,7 +50,7 @@ class RelationGraph:
         self.srcdata, self.dstdata = srcdata, dstdata
         self._csr: Optional[ops.CSRGraph] = None
         self.trusted = False  # ids already validated (edge lists derived from a checked graph)
-        self.regular_hint = None  # degree regularity inherited from the parent graph (edge dropout)
+        self.regular_hint = None  # (regular, regular_t) inherited from the parent graph (edge dropout)
 
     # -- the DGL surface the reference's layer code uses ---------------------------------
     def number_of_src_nodes(self) -> int:
@@ -90,8 +90,9 @@ class RelationGraph:
     @property
     def csr(self) -> ops.CSRGraph:
         if self._csr is None:
+            hint, hint_t = self.regular_hint if self.regular_hint is not None else (None, None)
             self._csr = ops.CSRGraph(self.dst, self.src, self.n_dst, self.n_src, check_range=not self.trusted,
-                                     regular=self.regular_hint)
+                                     regular=hint, regular_t=hint_t)
         return self._csr
 
 
@@ -339,7 +340,8 @@ def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
     for can in out.canonical_etypes:
         out[can].trusted = True  # a subset of an existing graph's edges: no range re-check, no host sync
         parent = graph[can]._csr
-        out[can].regular_hint = parent.regular if parent is not None else None  # dropping edges keeps it regular
+        # removing edges keeps a regular graph regular; unknown (None) stays conservative
+        out[can].regular_hint = (parent.regular, parent.regular_t) if parent is not None else None
     for nt in graph.ntypes:
         for k, v in graph.nodes[nt].data.items():
             out.nodes[nt].data[k] = v.clone()

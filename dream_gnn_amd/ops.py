@@ -297,7 +297,7 @@ class CSRGraph:
 
     def __init__(self, dst: torch.Tensor, src: torch.Tensor, n_dst: int, n_src: int,
                  vals: Optional[torch.Tensor] = None, check_range: bool = True, planned: bool = True,
-                 regular: Optional[bool] = None):
+                 regular: Optional[bool] = None, regular_t: Optional[bool] = None):
         _require_device(dst, src, vals)
         self.n_dst, self.n_src = int(n_dst), int(n_src)
         self._dst = dst.to(torch.int32).contiguous()
@@ -317,7 +317,9 @@ class CSRGraph:
         # (row, slice) segment sequentially) is safe to use.  Known after the one readback below;
         # unknown (False) for unchecked builds unless the caller vouches for it.
         self.regular = bool(regular) if regular is not None else False
-        self.regular_t = None
+        # same for the reversed graph; None = not known yet (resolved by one readback on the first
+        # backward of a validated graph, never for unchecked builds: those must not sync)
+        self.regular_t = regular_t if (regular_t is not None or check_range) else False
         if check_range:
             self._validate()
 
