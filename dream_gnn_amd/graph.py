@@ -317,6 +317,26 @@ def build_dec_graph(drug_ids: torch.Tensor, dis_ids: torch.Tensor, n_drug: int, 
                        {"drug": n_drug, "disease": n_dis}, device=device)
 
 
+def from_dgl(g) -> HeteroGraph:
+    """Convert a DGL heterograph (or anything with its accessor surface: ``canonical_etypes``,
+    ``ntypes``, ``number_of_nodes(nt)``, ``edges(etype=...)``, ``nodes[nt].data``) into a
+    :class:`HeteroGraph`, keeping edge order and node data (``ci``/``cj``).
+
+    DGL is not installable in this pipeline, so this is exercised against the accessor-compatible
+    stand-in used for fixture generation only (tests/test_host_logic.py); with a real DGL graph it
+    relies on those five public accessors and nothing else.
+    """
+    data = {}
+    for can in g.canonical_etypes:
+        src, dst = g.edges(etype=can)
+        data[tuple(can)] = (src, dst)
+    out = HeteroGraph(data, {nt: int(g.number_of_nodes(nt)) for nt in g.ntypes})
+    for nt in g.ntypes:
+        for key, val in g.nodes[nt].data.items():
+            out.nodes[nt].data[key] = val
+    return out
+
+
 def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
                         generator: Optional[torch.Generator] = None) -> HeteroGraph:
     """Edge dropout on the encoder graph — augmentation.py:13-89.

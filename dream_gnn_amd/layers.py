@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .graph import RelationGraph
+from .graph import HeteroGraph, RelationGraph, from_dgl
 
 
 class DGMIError(RuntimeError):
@@ -181,6 +181,22 @@ class HeteroGraphConv(nn.Module):
         return result
 
 
+_FOREIGN_GRAPHS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def _as_hetero(graph):
+    """Graphs that are not ours but expose DGL's accessor surface are converted once per object."""
+    if isinstance(graph, HeteroGraph) or not hasattr(graph, "canonical_etypes"):
+        return graph
+    try:
+        hit = _FOREIGN_GRAPHS.get(graph)
+    except TypeError:  # not weak-referenceable: convert every time
+        return from_dgl(graph).int()
+    if hit is None:
+        hit = _FOREIGN_GRAPHS[graph] = from_dgl(graph).int()
+    return hit
+
+
 class GCMCLayer(nn.Module):
     """layers.py:18-143.  Parameters: ``att`` (R,B), ``basis`` (B,in,msg), ``ufc`` (and ``ifc``,
     the same module when sharing), plus ``conv.mods.<etype>.weight`` in the unshared branch."""
@@ -253,6 +269,7 @@ class GCMCLayer(nn.Module):
             mod_args[name] = (w, Two_Stage)
             mod_args["rev-%s" % name] = (w, Two_Stage)
         inputs = {"drug": drug_feat, "disease": dis_feat}
+        graph = _as_hetero(graph)
         out = self._fused_conv(graph, inputs, mod_args) if self.fuse_relations and self.agg == "sum" else None
         if out is None:
             out = self.conv(graph, inputs, mod_args=mod_args)

@@ -12,7 +12,8 @@ DGL's documented semantics (sum over in-edges, multigraph, zero rows for isolate
 written with ``torch.index_add_`` so that it shares no code with ``oracle/``.  DGL's own kernel
 therefore stays **parity unpinned** — see DESIGN.md.
 
-Never imported by the product, by the tests, or on the GPU box.
+Never imported by the product or on the GPU box; besides gen_golden.py only one CPU
+host-logic test uses its graph class, as a DGL-*shaped* object to feed `graph.from_dgl`.
 """
 from __future__ import annotations
 

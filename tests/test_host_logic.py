@@ -168,3 +168,29 @@ def test_train_step_structure_on_cpu_backend():
 @pytest.mark.parametrize("name", ["n30_k4", "n12_k20"])
 def test_similarity_graph_builder(name):
     C.case_similarity_graph(CPU, name)
+
+
+def test_dgl_shaped_graph_is_accepted():
+    """A graph exposing DGL's accessor surface (here: the fixture generator's stand-in, DGL itself
+    being absent) goes straight into GCMCLayer and gives the reference's output."""
+    import sys
+
+    sys.path.insert(0, C.GOLD)
+    import dgl_standin
+
+    from dream_gnn_amd import graph as G, layers as L
+
+    g = C.load("gcmc_layer_shared_ini")
+    ours = C.build_enc(g, CPU)
+    foreign = dgl_standin.DGLGraph({can: ours.edges(etype=can) for can in ours.canonical_etypes},
+                                   {"drug": int(g["n_drug"]), "disease": int(g["n_dis"])})
+    for nt in ("drug", "disease"):
+        foreign.nodes[nt].data.update(ours.nodes[nt].data)
+    conv = G.from_dgl(foreign)
+    assert conv.canonical_etypes == ours.canonical_etypes and torch.equal(conv.nodes["drug"].data["ci"], ours.nodes["drug"].data["ci"])
+    uin, min_, msg, out, ini, share = [int(v) for v in g["cfg"]]
+    layer = C.load_sd(L.GCMCLayer([0, 1], uin, min_, msg, out, dropout_rate=0.0, agg="sum",
+                                  agg_act=L.get_activation("leaky"), ini=bool(ini), share_user_item_param=bool(share)), g, CPU)
+    o_drug, o_dis = layer(foreign, torch.from_numpy(g["drug"]), torch.from_numpy(g["dis"]))
+    C.close(o_drug, g["o_drug"], 1e-5, "o_drug")
+    C.close(o_dis, g["o_dis"], 1e-5, "o_dis")

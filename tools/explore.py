@@ -150,3 +150,48 @@ if "slicedcap" in which:
         ms_p = timeit(lambda: ops.spmm_csr_raw(g.indptr, g.indices, None, X, out=Y, plan=g.plan))
         print(f"avg degree {E/n_dst:6.1f}: sliced {ms_s*1e3:6.1f} us  planned {ms_p*1e3:6.1f} us  ratio {ms_p/ms_s:.2f}", flush=True)
         del g, sl
+if "torchref" in which:
+    # What the reference's own call (th.spmm on a sparse COO, layers.py:312) costs on this GPU through
+    # ATen/rocSPARSE, next to the HIP path, on the config-4 kNN-64 graph and the bipartite slice.
+    n = 100_000
+    r, c, v = synth.knn_sim_graph(n, 64, 2, dev)
+    X = torch.randn(n, 128, device=dev)
+    adj = torch.sparse_coo_tensor(torch.stack([r.long(), c.long()]), v, (n, n)).coalesce()
+    csr = adj.to_sparse_csr()
+    g = ops.CSRGraph(r, c, n, n, vals=v)
+    Y = torch.empty(n, 128, device=dev)
+    t_coo = timeit(lambda: torch.spmm(adj, X), n=10)
+    t_csr = timeit(lambda: csr @ X, n=10)
+    t_hip = timeit(lambda: g.spmm(X, out=Y))
+    print(f"kNN-64 N=100k nnz={g.nnz}: torch.spmm(COO) {t_coo*1e3:.0f} us | torch CSR @ {t_csr*1e3:.0f} us | HIP path {t_hip*1e3:.0f} us", flush=True)
+    xr = X.clone().requires_grad_(True)
+    def fb():
+        y = torch.spmm(adj, xr); y.backward(Y)
+    def fb_hip():
+        y = ops.spmm_csr(g, xr); y.backward(Y)
+    g.transposed()
+    print(f"   fwd+bwd: torch.spmm(COO) {timeit(fb, n=10)*1e3:.0f} us | HIP path {timeit(fb_hip)*1e3:.0f} us", flush=True)
+    nd, ns, E = 100_000, 50_000, 10_000_000
+    drug, dis = synth.bipartite_edges(nd, ns, E, 0, dev)
+    cj, ci = synth.degree_norm(drug, nd), synth.degree_norm(dis, ns)
+    Xd = torch.randn(nd, 128, device=dev)
+    gb = ops.CSRGraph(dis, drug, ns, nd)
+    Yb = torch.empty(ns, 128, device=dev)
+    def gcmc_torch():  # the update_all(copy_u, sum) stand-in a torch-only port would use
+        h = Xd * cj[:, None]
+        out = torch.zeros(ns, 128, device=dev).index_add_(0, dis.long(), h.index_select(0, drug.long()))
+        return out * ci[:, None]
+    t_t = timeit(gcmc_torch, n=5)
+    t_h = timeit(lambda: gb.spmm(Xd, cj, ci, out=Yb))
+    print(f"GCMC slice 10M edges: torch index_select+index_add_ {t_t*1e3:.0f} us | HIP path {t_h*1e3:.0f} us", flush=True)
+if "widths2" in which:
+    n_dst, n_src, E = 50_000, 100_000, 10_000_000
+    dst = torch.randint(0, n_dst, (E,), generator=gen, device=dev, dtype=torch.int32)
+    src = torch.randint(0, n_src, (E,), generator=gen, device=dev, dtype=torch.int32)
+    g = ops.CSRGraph(dst, src, n_dst, n_src)
+    for F in (32, 64, 128, 256, 344, 512):
+        X = torch.randn(n_src, F, device=dev)
+        Y = torch.empty(n_dst, F, device=dev)
+        ms = timeit(lambda: g.spmm(X, out=Y))
+        ms_p = timeit(lambda: ops.spmm_csr_raw(g.indptr, g.indices, None, X, out=Y, plan=g.plan))
+        print(f"F={F}: auto {ms*1e3:.0f} us ({'sliced' if g._use_sliced(F, n_dst, n_src, g.regular) else 'planned'}) planned {ms_p*1e3:.0f} us  {E*(4*F+4)/ms/1e6:.0f} GB/s alg", flush=True)
