@@ -75,6 +75,44 @@ __global__ __launch_bounds__(kBlock) void gather_concat_dword_kernel(
   }
 }
 
+// out[e] = A[src[e]] + B[dst[e]] (+ bias): VEC = 4 (16-B path) or 1; thread t handles element
+// group (t % W) of edge (t / W), W = F / VEC, grid-strided.
+template <int VEC, bool HAS_BIAS>
+__global__ __launch_bounds__(kBlock) void gather_add_kernel(
+    const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t E,
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+    const float* __restrict__ bias, int W, float* __restrict__ out, int64_t ldo) {
+  const int64_t total = E * W;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+    const int64_t e = t / W;
+    const int c = (int)(t - e * W) * VEC;
+    const float* a = A + (int64_t)src[e] * lda + c;
+    const float* b = B + (int64_t)dst[e] * ldb + c;
+    float* o = out + e * ldo + c;
+    if (VEC == 4) {
+      float4 x = *reinterpret_cast<const float4*>(a);
+      const float4 y = *reinterpret_cast<const float4*>(b);
+      x.x += y.x;
+      x.y += y.y;
+      x.z += y.z;
+      x.w += y.w;
+      if (HAS_BIAS) {
+        const float4 z = *reinterpret_cast<const float4*>(bias + c);
+        x.x += z.x;
+        x.y += z.y;
+        x.z += z.z;
+        x.w += z.w;
+      }
+      *reinterpret_cast<float4*>(o) = x;
+    } else {
+      float x = a[0] + b[0];
+      if (HAS_BIAS) x += bias[c];
+      o[0] = x;
+    }
+  }
+}
+
 inline unsigned grid_for(int64_t n) {
   int64_t b = (n + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
@@ -106,6 +144,32 @@ hipError_t gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, 
     const int W = (int)(Fa + Fb);
     hipLaunchKernelGGL(gather_concat_dword_kernel, dim3(grid_for(E * W)), dim3(kBlock), 0, s, src,
                        dst, E, A, lda, (int)Fa, B, ldb, W, out, ldo);
+  }
+  return hipGetLastError();
+}
+
+hipError_t gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A, int64_t lda,
+                          const float* B, int64_t ldb, const float* bias, int64_t F, float* out,
+                          int64_t ldo, hipStream_t s) {
+  if (E == 0 || F == 0) return hipSuccess;
+  const bool vec = (F % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (ldo % 4 == 0) && al16(A) &&
+                   al16(B) && al16(out) && (bias == nullptr || al16(bias));
+  if (vec) {
+    const int W = (int)(F / 4);
+    if (bias)
+      hipLaunchKernelGGL((gather_add_kernel<4, true>), dim3(grid_for(E * W)), dim3(kBlock), 0, s, src, dst, E,
+                         A, lda, B, ldb, bias, W, out, ldo);
+    else
+      hipLaunchKernelGGL((gather_add_kernel<4, false>), dim3(grid_for(E * W)), dim3(kBlock), 0, s, src, dst, E,
+                         A, lda, B, ldb, bias, W, out, ldo);
+  } else {
+    const int W = (int)F;
+    if (bias)
+      hipLaunchKernelGGL((gather_add_kernel<1, true>), dim3(grid_for(E * W)), dim3(kBlock), 0, s, src, dst, E,
+                         A, lda, B, ldb, bias, W, out, ldo);
+    else
+      hipLaunchKernelGGL((gather_add_kernel<1, false>), dim3(grid_for(E * W)), dim3(kBlock), 0, s, src, dst, E,
+                         A, lda, B, ldb, bias, W, out, ldo);
   }
   return hipGetLastError();
 }

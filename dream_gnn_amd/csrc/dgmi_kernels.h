@@ -97,6 +97,11 @@ hipError_t gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, 
                              int64_t lda, int64_t Fa, const float* B, int64_t ldb, int64_t Fb,
                              float* out, int64_t ldo, hipStream_t s);
 
+// out[e] = A[src[e]] + B[dst[e]] (+ bias)   (dgmi_edge.hip)
+hipError_t gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A, int64_t lda,
+                          const float* B, int64_t ldb, const float* bias, int64_t F, float* out,
+                          int64_t ldo, hipStream_t s);
+
 hipError_t gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,
                       hipStream_t s);
 

@@ -96,6 +96,61 @@ class RelationGraph:
         return self._csr
 
 
+class DroppedRelation(RelationGraph):
+    """A relation after edge dropout (augmentation.py:13-89), kept as *parent relation + kept edge
+    positions* instead of a re-sorted copy.
+
+    The kept edge list (``src`` / ``dst``, in the order of the random permutation prefix, as the
+    reference builds it) is materialised only if somebody asks for it.  ``csr`` is a value view of
+    the parent's CSR with a 0/1 keep mask as edge values: no sort, no plan rebuild, no host sync —
+    the per-iteration graph churn of train.py:267 becomes one ``randperm`` and a few gathers.
+    Dropped edges contribute ``0 * x`` to the sums (identical to removing them for finite x).
+    """
+
+    def __init__(self, parent: RelationGraph, keep_idx: torch.Tensor, srcdata: dict, dstdata: dict):
+        self.canonical = parent.canonical
+        self.parent = parent
+        self.keep_idx = keep_idx
+        self.n_src, self.n_dst = parent.n_src, parent.n_dst
+        self.srcdata, self.dstdata = srcdata, dstdata
+        self._csr = None
+        self._pairs = None
+        self._lists = None
+        self.trusted = True
+        self.regular_hint = None
+
+    def _materialise(self):
+        if self._lists is None:
+            self._lists = (self.parent.src[self.keep_idx], self.parent.dst[self.keep_idx])
+        return self._lists
+
+    src = property(lambda self: self._materialise()[0], lambda self, v: self._set(0, v))
+    dst = property(lambda self: self._materialise()[1], lambda self, v: self._set(1, v))
+
+    def _set(self, i, v):
+        lists = list(self._materialise())
+        lists[i] = v
+        self._lists = tuple(lists)
+
+    def number_of_edges(self) -> int:
+        return int(self.keep_idx.shape[0])
+
+    @property
+    def device(self):
+        return self.keep_idx.device
+
+    def keep_mask(self) -> torch.Tensor:
+        """float 0/1 over the parent's edges."""
+        m = torch.zeros(self.parent.number_of_edges(), dtype=torch.float32, device=self.keep_idx.device)
+        return m.index_fill_(0, self.keep_idx, 1.0)  # (m[idx] = 1.0 would synchronise with the host)
+
+    @property
+    def csr(self) -> ops.CSRGraph:
+        if self._csr is None:
+            self._csr = self.parent.csr.masked(self.keep_mask())
+        return self._csr
+
+
 class HeteroGraph:
     """Bipartite heterograph: ``{(src_type, etype, dst_type): (src_ids, dst_ids)}``.
 
@@ -233,6 +288,13 @@ class HeteroGraph:
             return cache[dst_type]
         cans = [c for c in self._rels if c[2] == dst_type]
         out = None
+        parent = self.__dict__.get("_dropout_parent")
+        if parent is not None and all(isinstance(self._rels[c], DroppedRelation) for c in cans):
+            base = parent.fused_relations(dst_type)  # built (and validated) once on the parent
+            if base is not None and base[1] == cans:
+                mask = torch.cat([self._rels[c].keep_mask() for c in cans])
+                cache[dst_type] = (base[0].masked(mask), cans)
+                return cache[dst_type]
         if cans and len({c[0] for c in cans}) == 1 and len({self._rels[c].src.device for c in cans}) == 1:
             R = len(cans)
             rels = [self._rels[c] for c in cans]
@@ -344,24 +406,33 @@ def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
     Per edge type independently, keep the first ``max(1, int(E*(1-p)))`` entries of a random
     permutation (so ``rev-r`` stops being the transpose of ``r``); node data is *copied, not
     recomputed* (augmentation.py:68-70), so ``ci``/``cj`` go stale exactly as in the reference.
-    The new graph's CSRs are rebuilt on the device on first use.
+    The result holds, per relation, the parent relation and the kept positions
+    (:class:`DroppedRelation`): its products run on the parent's CSRs with a keep mask as edge
+    values — nothing is re-sorted and nothing synchronises with the host.
     """
-    data = {}
+    out = HeteroGraph({}, {nt: graph.number_of_nodes(nt) for nt in graph.ntypes})
+    nested = False
     for can in graph.canonical_etypes:
         rel = graph[can]
+        st, _, dt = can
         E = rel.number_of_edges()
-        if E == 0:
-            data[can] = (rel.src, rel.dst)
+        if isinstance(rel, DroppedRelation):  # dropout of a dropout: go through the materialised lists
+            nested = True
+        if E == 0 or isinstance(rel, DroppedRelation):
+            src, dst = rel.src, rel.dst
+            if E:
+                keep = max(1, int(E * (1 - dropout_rate)))
+                perm = torch.randperm(E, device=rel.device, generator=generator)[:keep]
+                src, dst = src[perm], dst[perm]
+            child = RelationGraph(can, src, dst, rel.n_src, rel.n_dst, out._ndata[st], out._ndata[dt])
+            child.trusted = True  # a subset of an existing graph's edges: no range re-check, no host sync
+            out._rels[can] = child
             continue
         keep = max(1, int(E * (1 - dropout_rate)))
         perm = torch.randperm(E, device=rel.device, generator=generator)[:keep]
-        data[can] = (rel.src[perm], rel.dst[perm])
-    out = HeteroGraph(data, {nt: graph.number_of_nodes(nt) for nt in graph.ntypes})
-    for can in out.canonical_etypes:
-        out[can].trusted = True  # a subset of an existing graph's edges: no range re-check, no host sync
-        parent = graph[can]._csr
-        # removing edges keeps a regular graph regular; unknown (None) stays conservative
-        out[can].regular_hint = (parent.regular, parent.regular_t) if parent is not None else None
+        out._rels[can] = DroppedRelation(rel, perm, out._ndata[st], out._ndata[dt])
+    if not nested:
+        out.__dict__["_dropout_parent"] = graph
     for nt in graph.ntypes:
         for k, v in graph.nodes[nt].data.items():
             out.nodes[nt].data[k] = v.clone()
@@ -378,6 +449,10 @@ def random_edge_dropout_sparse(adj: torch.Tensor, dropout_rate: float = 0.1,
     perm = torch.randperm(E, device=adj.device, generator=generator)[:keep]
     out = torch.sparse_coo_tensor(idx[:, perm], val[perm], adj.shape, device=adj.device)
     out._dgmi_trusted = True  # a subset of a valid adjacency: adjacency_csr skips the id re-check (no host sync)
+    # layers.adjacency_csr applies the dropout as a keep mask over the parent's CSR instead of
+    # re-sorting these entries (same multiset of entries, hence the same product)
+    out._dgmi_parent = adj
+    out._dgmi_keep_idx = perm
     return out
 
 

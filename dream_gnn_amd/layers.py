@@ -332,6 +332,11 @@ class GCMCLayer(nn.Module):
 _ADJ_CACHE: Dict[int, tuple] = {}
 
 
+def _prune_adj_cache():
+    for k in [k for k, v in _ADJ_CACHE.items() if v[0]() is None]:
+        del _ADJ_CACHE[k]
+
+
 def adjacency_csr(adj) -> ops.CSRGraph:
     """CSR (+ lazily its transpose) of a torch sparse COO adjacency, cached per tensor object.
 
@@ -348,14 +353,21 @@ def adjacency_csr(adj) -> ops.CSRGraph:
         return hit[2]
     if not adj.is_sparse:
         raise RuntimeError("GraphConvolution expects a sparse COO adjacency or a CSRGraph")
+    parent = getattr(adj, "_dgmi_parent", None)
+    if parent is not None:  # edge-dropped copy made by graph.random_edge_dropout_sparse
+        base = adjacency_csr(parent)
+        keep = torch.zeros(base.nnz, dtype=torch.float32, device=adj.device).index_fill_(0, adj._dgmi_keep_idx, 1.0)
+        g = base.masked(keep)
+        _prune_adj_cache()
+        _ADJ_CACHE[key] = (weakref.ref(adj), adj._version, g)
+        return g
     idx, val = adj._indices(), adj._values()
     n_dst, n_src = adj.shape
     if max(n_dst, n_src) >= 2 ** 31 - 1:
         raise RuntimeError("adjacency too large for int32 ids")
     g = ops.CSRGraph(idx[0].to(torch.int32), idx[1].to(torch.int32), n_dst, n_src, vals=val,
                      check_range=not getattr(adj, "_dgmi_trusted", False))
-    for k in [k for k, v in _ADJ_CACHE.items() if v[0]() is None]:
-        del _ADJ_CACHE[k]
+    _prune_adj_cache()
     _ADJ_CACHE[key] = (weakref.ref(adj), adj._version, g)
     return g
 

@@ -51,11 +51,24 @@ class MLPDecoder(nn.Module):
         for lin in (self.lin1, self.lin2, self.lin3):
             lin.reset_parameters()
 
+    #: lin1(cat(h_src, h_dst)) = h_src W_a^T + h_dst W_b^T + b: project the node tables, then add the
+    #: projected rows per edge (``dgmi_gather_add_f32``).  Removes the E x 2F matrix and the
+    #: E x 2F x 128 GEMM; same parameters, results equal up to fp32 summation order.  False: the
+    #: reference's literal order (gather-concat, then lin1 over edges).
+    fuse_lin1 = True
+
     def forward(self, graph, drug_feat, dis_feat):
-        # layers.py:361-365: graph.apply_edges(udf_u_mul_e) -> edata['m'] = cat(h_src, h_dst);
-        # here one fused HIP gather-concat over the decoder edge list (bit-identical values).
-        out = ops.gather_concat(graph.edge_pairs(), drug_feat, dis_feat)
-        out = self.dropout(F.relu(self.lin1(out)))
+        pairs = graph.edge_pairs()
+        if self.fuse_lin1:
+            Fd = drug_feat.shape[1]
+            w = self.lin1.weight
+            out = ops.gather_add(pairs, drug_feat @ w[:, :Fd].t(), dis_feat @ w[:, Fd:].t(), self.lin1.bias)
+            out = self.dropout(F.relu(out))
+        else:
+            # layers.py:361-365: graph.apply_edges(udf_u_mul_e) -> edata['m'] = cat(h_src, h_dst);
+            # one fused HIP gather-concat over the decoder edge list (bit-identical values).
+            out = ops.gather_concat(pairs, drug_feat, dis_feat)
+            out = self.dropout(F.relu(self.lin1(out)))
         out = self.dropout(F.relu(self.lin2(out)))
         return self.lin3(out)
 

@@ -249,7 +249,11 @@ class SlicedCSR:
         self.vals = None if vals is None else gather_f32(vals, self.eid)
         self._pbytes = {}
 
-    def spmm(self, X, src_scale=None, dst_scale=None, out=None):
+    _DEFAULT = object()
+
+    def spmm(self, X, src_scale=None, dst_scale=None, out=None, vals=_DEFAULT):
+        """``vals`` (in sliced order, see ``eid``) overrides the values given at construction."""
+        vals = self.vals if vals is SlicedCSR._DEFAULT else vals
         dev = self.segptr.device
         if not X.is_cuda or X.device != dev:
             _require_device(self.segptr, X)
@@ -267,7 +271,7 @@ class SlicedCSR:
             if pbytes is None:
                 pbytes = self._pbytes[F] = int(_L.dgmi_spmm_sliced_planes_bytes(self.n_dst, self.n_slices, F))
             planes = torch.empty(pbytes, dtype=torch.uint8, device=dev)
-            _lib.check(_L.dgmi_spmm_sliced_f32(self.segptr.data_ptr(), self.indices.data_ptr(), _ptr(self.vals),
+            _lib.check(_L.dgmi_spmm_sliced_f32(self.segptr.data_ptr(), self.indices.data_ptr(), _ptr(vals),
                                                X.data_ptr(), ldx, _ptr(src_scale), _ptr(dst_scale), out.data_ptr(),
                                                F, self.n_dst, self.n_src, F, self.n_slices, planes.data_ptr(), pbytes,
                                                _stream(dev)), "dgmi_spmm_sliced_f32")
@@ -284,85 +288,139 @@ SLICED_MAX_TABLE_BYTES = 160 << 20
 SLICED_MIN_AVG_DEGREE = 64
 
 
+class _Structure:
+    """Everything about a CSRGraph that depends on the edge list only (shared by value views)."""
+
+    __slots__ = ("n_dst", "n_src", "dst", "src", "indptr", "indices", "eid", "plan", "planned", "t",
+                 "sliced", "sliced_t", "regular", "regular_t")
+
+
 class CSRGraph:
     """A relation slice / sparse adjacency in the layout the kernels read.
 
-    Holds the destination-major CSR (forward: ``Y = A X``) and, built lazily on first
-    backward, the source-major CSR of the reversed edges (``dX = A^T dY``), both made by the
-    device COO->CSR, each with its launch plan.  ``vals`` (optional) are per-edge values in
-    the caller's COO order.  Row = destination, col = source, as in ``th.spmm(adj, x)`` where
-    ``adj[dst, src]``.  ``check_range=True`` costs one host sync (error-flag readback); pass
-    ``False`` for edge lists derived from an already validated graph (edge dropout).
+    Structure (shared, built once): the destination-major CSR (forward ``Y = A X``), lazily the
+    source-major CSR of the reversed edges (``dX = A^T dY``) and the XCD-sliced layouts, each
+    with its launch plan, all made by the device COO->CSR.  Values (per view): optional per-edge
+    values in the caller's COO order, permuted on demand into each layout.  Row = destination,
+    col = source, as in ``th.spmm(adj, x)`` where ``adj[dst, src]``.
+
+    ``check_range=True`` costs one host sync (id range + maximum degree readback); pass ``False``
+    for edge lists derived from an already validated graph.  :meth:`with_values` gives a view of
+    the same structure with other edge values — how edge dropout is applied without re-sorting
+    (a 0/1 keep mask as values).
     """
 
     def __init__(self, dst: torch.Tensor, src: torch.Tensor, n_dst: int, n_src: int,
                  vals: Optional[torch.Tensor] = None, check_range: bool = True, planned: bool = True,
                  regular: Optional[bool] = None, regular_t: Optional[bool] = None):
         _require_device(dst, src, vals)
-        self.n_dst, self.n_src = int(n_dst), int(n_src)
-        self._dst = dst.to(torch.int32).contiguous()
-        self._src = src.to(torch.int32).contiguous()
-        self._coo_vals = None if vals is None else vals.to(torch.float32).contiguous()
-        if self._coo_vals is not None and self._coo_vals.shape[0] != self._dst.shape[0]:
+        S = self._S = _Structure()
+        S.n_dst, S.n_src = int(n_dst), int(n_src)
+        S.dst = dst.to(torch.int32).contiguous()
+        S.src = src.to(torch.int32).contiguous()
+        if vals is not None and vals.shape[0] != S.dst.shape[0]:
             raise RuntimeError("vals/edge-list length mismatch")
-        self.indptr, self.indices, self.eid = csr_from_coo(self._dst, self._src, self.n_dst, self.n_src,
-                                                           check_range=False)
-        self.vals = None if self._coo_vals is None else gather_f32(self._coo_vals, self.eid)
-        self._planned = planned
-        self.plan = build_plan(self.indptr, self.nnz) if planned else None
-        self._t = None
-        self._sliced = None      # lazily built SlicedCSR of the forward direction
-        self._sliced_t = None
+        S.indptr, S.indices, S.eid = csr_from_coo(S.dst, S.src, S.n_dst, S.n_src, check_range=False)
+        S.planned = planned
+        S.plan = build_plan(S.indptr, int(S.indices.shape[0])) if planned else None
+        S.t = S.sliced = S.sliced_t = None
         # `regular`: no destination row is extremely long, so the XCD-local kernel (which walks a
         # (row, slice) segment sequentially) is safe to use.  Known after the one readback below;
-        # unknown (False) for unchecked builds unless the caller vouches for it.
-        self.regular = bool(regular) if regular is not None else False
-        # same for the reversed graph; None = not known yet (resolved by one readback on the first
-        # backward of a validated graph, never for unchecked builds: those must not sync)
-        self.regular_t = regular_t if (regular_t is not None or check_range) else False
+        # False for unchecked builds unless the caller vouches for it (they must not sync).
+        S.regular = bool(regular) if regular is not None else False
+        S.regular_t = regular_t if (regular_t is not None or check_range) else False
+        self._set_values(None if vals is None else vals.to(torch.float32).contiguous())
         if check_range:
             self._validate()
 
+    # -- values -----------------------------------------------------------------------------------
+    def _set_values(self, coo_vals):
+        self._coo_vals = coo_vals
+        self._v = {}  # layout name -> values permuted into that layout
+
+    def with_values(self, coo_vals: Optional[torch.Tensor]) -> "CSRGraph":
+        """A view sharing this graph's structure (and whatever it builds later) with other per-edge
+        values, given in the original COO edge order."""
+        if coo_vals is not None and coo_vals.shape[0] != self.nnz:
+            raise RuntimeError("expected %d edge values, got %d" % (self.nnz, coo_vals.shape[0]))
+        view = object.__new__(CSRGraph)
+        view._S = self._S
+        view._set_values(None if coo_vals is None else coo_vals.to(torch.float32).contiguous())
+        return view
+
+    def masked(self, keep: torch.Tensor) -> "CSRGraph":
+        """View with edge e weighted by ``keep[e]`` (0/1), times the existing values if any."""
+        keep = keep.to(torch.float32)
+        return self.with_values(keep if self._coo_vals is None else self._coo_vals * keep)
+
+    def _vals_for(self, layout: str, eid: torch.Tensor):
+        if self._coo_vals is None:
+            return None
+        v = self._v.get(layout)
+        if v is None:
+            v = self._v[layout] = gather_f32(self._coo_vals, eid)
+        return v
+
+    # -- structure accessors (kept as attributes of the public surface) ----------------------------
+    n_dst = property(lambda self: self._S.n_dst)
+    n_src = property(lambda self: self._S.n_src)
+    indptr = property(lambda self: self._S.indptr)
+    indices = property(lambda self: self._S.indices)
+    eid = property(lambda self: self._S.eid)
+    plan = property(lambda self: self._S.plan)
+    regular = property(lambda self: self._S.regular)
+    regular_t = property(lambda self: self._S.regular_t)
+    _sliced = property(lambda self: self._S.sliced)
+    _sliced_t = property(lambda self: self._S.sliced_t)
+
+    @property
+    def vals(self):
+        """Edge values in CSR order (None for an unweighted graph)."""
+        return self._vals_for("csr", self._S.eid)
+
     @property
     def nnz(self) -> int:
-        return int(self.indices.shape[0])
+        return int(self._S.indices.shape[0])
 
     @property
     def device(self):
-        return self.indptr.device
+        return self._S.indptr.device
 
     @staticmethod
     def _is_regular(max_deg: int, nnz: int, n_rows: int) -> bool:
         return max_deg <= max(256, 8 * (nnz // max(n_rows, 1)))
 
     def _validate(self):
-        """One host sync: id range check (row ids via the sort's key range, column ids here) and
-        the maximum in-degree."""
+        """One host sync: id range check and the maximum in-degree."""
+        S = self._S
         if self.nnz == 0:
-            self.regular = True
+            S.regular = True
             return
-        stats = torch.stack([self._dst.min(), self._dst.max(), self._src.min(), self._src.max(),
-                             (self.indptr[1:] - self.indptr[:-1]).max()]).tolist()
+        stats = torch.stack([S.dst.min(), S.dst.max(), S.src.min(), S.src.max(),
+                             (S.indptr[1:] - S.indptr[:-1]).max()]).tolist()
         dlo, dhi, slo, shi, max_deg = (int(v) for v in stats)
-        if dlo < 0 or dhi >= self.n_dst:
-            raise RuntimeError("destination id out of range [0, %d): min %d max %d" % (self.n_dst, dlo, dhi))
-        if slo < 0 or shi >= self.n_src:
-            raise RuntimeError("source id out of range [0, %d): min %d max %d" % (self.n_src, slo, shi))
-        self.regular = self._is_regular(max_deg, self.nnz, self.n_dst)
+        if dlo < 0 or dhi >= S.n_dst:
+            raise RuntimeError("destination id out of range [0, %d): min %d max %d" % (S.n_dst, dlo, dhi))
+        if slo < 0 or shi >= S.n_src:
+            raise RuntimeError("source id out of range [0, %d): min %d max %d" % (S.n_src, slo, shi))
+        S.regular = self._is_regular(max_deg, self.nnz, S.n_dst)
 
     def _use_sliced(self, F: int, n_rows: int, n_cols: int, regular: bool) -> bool:
         table = n_cols * F * 4
-        return (regular and F % 4 == 0 and SLICED_MIN_TABLE_BYTES <= table <= SLICED_MAX_TABLE_BYTES
+        return (bool(regular) and F % 4 == 0 and SLICED_MIN_TABLE_BYTES <= table <= SLICED_MAX_TABLE_BYTES
                 and self.nnz >= SLICED_MIN_AVG_DEGREE * n_rows and n_rows * SlicedCSR.N_SLICES < 2 ** 31 - 1)
+
+    def _t_struct(self):
+        S = self._S
+        if S.t is None:
+            indptr_t, indices_t, eid_t = csr_from_coo(S.src, S.dst, S.n_src)
+            S.t = (indptr_t, indices_t, eid_t, build_plan(indptr_t, self.nnz) if S.planned else None)
+        return S.t
 
     def transposed(self):
         """(indptr_t, indices_t, vals_t, plan_t): CSR of the reversed edges, rows = source nodes."""
-        if self._t is None:
-            indptr_t, indices_t, eid_t = csr_from_coo(self._src, self._dst, self.n_src)
-            vals_t = None if self._coo_vals is None else gather_f32(self._coo_vals, eid_t)
-            plan_t = build_plan(indptr_t, self.nnz) if self._planned else None
-            self._t = (indptr_t, indices_t, vals_t, plan_t)
-        return self._t
+        indptr_t, indices_t, eid_t, plan_t = self._t_struct()
+        return indptr_t, indices_t, self._vals_for("csr_t", eid_t), plan_t
 
     def _run(self, indptr, indices, vals, plan, n_rows, n_cols, X, col_scale, row_scale, out):
         dev = indptr.device
@@ -383,24 +441,26 @@ class CSRGraph:
         """``diag(dst_scale) A diag(src_scale) X`` (no autograd).  Picks the XCD-local sliced
         kernel when the feature table is a few L2s large and the graph is regular, else the
         planned kernel."""
-        if X.dim() == 2 and self._use_sliced(X.shape[1], self.n_dst, self.n_src, self.regular) and _sliced_ok(X, out):
-            if self._sliced is None:
-                self._sliced = SlicedCSR(self._dst, self._src, self.n_dst, self.n_src, vals=self._coo_vals)
-            return self._sliced.spmm(X, src_scale, dst_scale, out)
-        return self._run(self.indptr, self.indices, self.vals, self.plan, self.n_dst, self.n_src, X,
-                         src_scale, dst_scale, out)
+        S = self._S
+        if X.dim() == 2 and self._use_sliced(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
+            if S.sliced is None:
+                S.sliced = SlicedCSR(S.dst, S.src, S.n_dst, S.n_src)
+            return S.sliced.spmm(X, src_scale, dst_scale, out, vals=self._vals_for("sliced", S.sliced.eid))
+        return self._run(S.indptr, S.indices, self.vals, S.plan, S.n_dst, S.n_src, X, src_scale, dst_scale, out)
 
     def spmm_t(self, dY, src_scale=None, dst_scale=None, out=None):
         """``diag(src_scale) A^T diag(dst_scale) dY`` — the backward of :meth:`spmm`."""
-        indptr_t, indices_t, vals_t, plan_t = self.transposed()
-        if self.regular_t is None:  # one-time readback of the reversed graph's maximum degree
+        S = self._S
+        indptr_t, indices_t, eid_t, plan_t = self._t_struct()
+        if S.regular_t is None:  # one-time readback of the reversed graph's maximum degree
             max_deg = int((indptr_t[1:] - indptr_t[:-1]).max()) if self.nnz else 0
-            self.regular_t = self.regular and self._is_regular(max_deg, self.nnz, self.n_src)
-        if dY.dim() == 2 and self._use_sliced(dY.shape[1], self.n_src, self.n_dst, self.regular_t) and _sliced_ok(dY, out):
-            if self._sliced_t is None:
-                self._sliced_t = SlicedCSR(self._src, self._dst, self.n_src, self.n_dst, vals=self._coo_vals)
-            return self._sliced_t.spmm(dY, dst_scale, src_scale, out)
-        return self._run(indptr_t, indices_t, vals_t, plan_t, self.n_src, self.n_dst, dY, dst_scale, src_scale, out)
+            S.regular_t = bool(S.regular) and self._is_regular(max_deg, self.nnz, S.n_src)
+        if dY.dim() == 2 and self._use_sliced(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):
+            if S.sliced_t is None:
+                S.sliced_t = SlicedCSR(S.src, S.dst, S.n_src, S.n_dst)
+            return S.sliced_t.spmm(dY, dst_scale, src_scale, out, vals=self._vals_for("sliced_t", S.sliced_t.eid))
+        return self._run(indptr_t, indices_t, self._vals_for("csr_t", eid_t), plan_t, S.n_src, S.n_dst, dY,
+                         dst_scale, src_scale, out)
 
 
 class _SpMM(torch.autograd.Function):
@@ -514,3 +574,46 @@ class _GatherConcat(torch.autograd.Function):
 def gather_concat(pairs: EdgePairs, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     """Differentiable ``cat(A[src], B[dst])`` over the decoder edges."""
     return _GatherConcat.apply(A, B, pairs)
+
+
+def gather_add_raw(src, dst, A, B, bias=None, out=None) -> torch.Tensor:
+    """``out[e] = A[src[e]] + B[dst[e]] (+ bias)`` through ``dgmi_gather_add_f32`` (no autograd)."""
+    dev = _require_device(src, dst, A, B, bias, out)
+    _check(src, torch.int32, "src", 1)
+    _check(dst, torch.int32, "dst", 1)
+    A, _, F, lda = _prep_dense(A)
+    B, _, Fb, ldb = _prep_dense(B)
+    if F != Fb:
+        raise RuntimeError("A and B must have the same width, got %d and %d" % (F, Fb))
+    if bias is not None:
+        _check(bias, torch.float32, "bias", 1)
+        if bias.shape[0] != F:
+            raise RuntimeError("bias has %d entries, expected %d" % (bias.shape[0], F))
+    E = src.shape[0]
+    if out is None:
+        out = torch.empty((E, F), dtype=torch.float32, device=dev)
+    with _guard(dev):
+        _lib.check(_L.dgmi_gather_add_f32(_ptr(src), _ptr(dst), E, _ptr(A), lda, _ptr(B), ldb, _ptr(bias), F,
+                                          _ptr(out), max(F, 1), _stream(dev)), "dgmi_gather_add_f32")
+    return out
+
+
+class _GatherAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, B, bias, pairs: EdgePairs):
+        ctx.pairs = pairs
+        return gather_add_raw(pairs.src, pairs.dst, A, B, bias)
+
+    @staticmethod
+    def backward(ctx, dOut):
+        pairs = ctx.pairs
+        dOut = dOut.contiguous()
+        dA = pairs.by_src().spmm(dOut) if ctx.needs_input_grad[0] else None
+        dB = pairs.by_dst().spmm(dOut) if ctx.needs_input_grad[1] else None
+        dbias = dOut.sum(0) if ctx.needs_input_grad[2] else None
+        return dA, dB, dbias, None
+
+
+def gather_add(pairs: EdgePairs, A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """Differentiable ``A[src] + B[dst] (+ bias)`` over the decoder edges."""
+    return _GatherAdd.apply(A, B, bias, pairs)

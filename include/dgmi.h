@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 5
+#define DGMI_ABI_VERSION 6
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -202,6 +202,18 @@ DGMI_API int dgmi_gather_concat_f32(const int32_t* src, const int32_t* dst, int6
                                     const float* A, int64_t lda, int64_t Fa, const float* B,
                                     int64_t ldb, int64_t Fb, float* out, int64_t ldo,
                                     dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
+ * (f2) Per-edge gather-add: out[e, :] = A[src[e], :] + B[dst[e], :] (+ bias[:]).
+ * The decoder's first Linear applied to cat(h_src, h_dst) (layers.py:364-367) is linear in the two
+ * halves: lin1(cat(a, b)) = a W_a^T + b W_b^T + bias.  Projecting the NODE tables first
+ * (two N x F x H GEMMs) and adding the projected rows per edge avoids materialising the E x 2F
+ * matrix and the E x 2F x H GEMM altogether.  Same bytes-per-edge shape as the gather-concat:
+ * bound by the streaming write of E*4*F bytes.  bias may be NULL.
+ */
+DGMI_API int dgmi_gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
+                                 int64_t lda, const float* B, int64_t ldb, const float* bias,
+                                 int64_t F, float* out, int64_t ldo, dgmi_stream_t stream);
 
 #ifdef __cplusplus
 }

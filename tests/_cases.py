@@ -195,7 +195,7 @@ def net_args(g):
                                  attention_dropout=0.0, beta=0.1)
 
 
-def case_net(dev):
+def case_net(dev, fuse_decoder=True):
     from dream_gnn_amd import graph as G, model as M
 
     g = load("net_mini")
@@ -203,6 +203,7 @@ def case_net(dev):
     args = net_args(g)
     net = load_sd(M.Net(args), g, dev)  # the reference's state_dict loads strict=True
     net.train()
+    net.decoder.fuse_lin1 = fuse_decoder
     enc = build_enc(g, dev)
     dec = G.build_dec_graph(torch.from_numpy(g["dec_src"]), torch.from_numpy(g["dec_dst"]), nd, ns, device=dev).int()
     pred, drug_out, drug_sim_out, dis_out, dis_sim_out = net(

@@ -158,11 +158,21 @@ def test_edge_dropout_rebuild_full_size(cfg4, dev):
     for et in ("0", "rev-0"):
         rel = dropped[et]
         assert rel.number_of_edges() == max(1, int(E * 0.9)) and rel.trusted
-        csr = rel.csr
-        deg = torch.bincount(rel.dst.long(), minlength=rel.n_dst)
-        assert torch.equal(csr.indptr[1:] - csr.indptr[:-1], deg.int())
+        csr = rel.csr  # a keep-mask view of the parent's CSR: same structure, no re-sort
+        assert csr.indptr is hg[et].csr.indptr and csr.nnz == E
+        deg = torch.bincount(rel.dst.long(), minlength=rel.n_dst)  # kept edges, materialised on demand
         ones = csr.spmm(torch.ones(rel.n_src, 8, device=dev))
         assert torch.equal(ones[:, 0], deg.float())
+        # same product as a CSR rebuilt from the kept edge list (the reference's construction)
+        from dream_gnn_amd import ops
+
+        X = torch.randn(rel.n_src, 128, device=dev)
+        rebuilt = ops.CSRGraph(rel.dst, rel.src, rel.n_dst, rel.n_src, check_range=False)
+        a, b = csr.spmm(X), rebuilt.spmm(X)
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+        W = torch.randn(rel.n_dst, 128, device=dev)
+        a, b = csr.spmm_t(W), rebuilt.spmm_t(W)
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
     # the two directions were dropped independently: rev-0 is no longer the transpose of 0
     a = torch.sort(dropped["0"].src.long() * NS + dropped["0"].dst.long())[0]
     b = torch.sort(dropped["rev-0"].dst.long() * NS + dropped["rev-0"].src.long())[0]

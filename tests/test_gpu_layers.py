@@ -37,8 +37,9 @@ def test_graphconv_nobias(dev):
     C.case_graphconv_nobias(dev)
 
 
-def test_net_forward_loss_grads(dev):
-    C.case_net(dev)
+@pytest.mark.parametrize("fuse_decoder", [True, False])
+def test_net_forward_loss_grads(dev, fuse_decoder):
+    C.case_net(dev, fuse_decoder)
 
 
 @pytest.mark.parametrize("symm", [1, 0])

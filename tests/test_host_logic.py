@@ -47,8 +47,9 @@ def test_graphconv_nobias():
     C.case_graphconv_nobias(CPU)
 
 
-def test_net_forward_loss_grads():
-    C.case_net(CPU)
+@pytest.mark.parametrize("fuse_decoder", [True, False])
+def test_net_forward_loss_grads(fuse_decoder):
+    C.case_net(CPU, fuse_decoder)
 
 
 @pytest.mark.parametrize("symm", [1, 0])
@@ -194,3 +195,39 @@ def test_dgl_shaped_graph_is_accepted():
     o_drug, o_dis = layer(foreign, torch.from_numpy(g["drug"]), torch.from_numpy(g["dis"]))
     C.close(o_drug, g["o_drug"], 1e-5, "o_drug")
     C.close(o_dis, g["o_dis"], 1e-5, "o_dis")
+
+
+def test_edge_dropout_is_a_mask_view_with_the_same_product():
+    """augmentation.py:13-124 without re-sorting: the dropped graph's product equals the product
+    over a CSR rebuilt from its (materialised) kept edge lists; same for the sparse adjacency."""
+    from dream_gnn_amd import graph as G, layers as L, ops
+
+    g = C.load("gcmc_layer_shared_ini")
+    enc = C.build_enc(g, CPU)
+    torch.manual_seed(3)
+    child = G.random_edge_dropout(enc, 0.3)
+    X = {"drug": torch.randn(int(g["n_drug"]), 8), "disease": torch.randn(int(g["n_dis"]), 8)}
+    for can in enc.canonical_etypes:
+        rel, base = child[can], enc[can]
+        assert isinstance(rel, G.DroppedRelation) and rel.number_of_edges() == max(1, int(base.number_of_edges() * 0.7))
+        assert rel.csr.indptr is base.csr.indptr  # structure shared, not rebuilt
+        rebuilt = ops.CSRGraph(rel.dst, rel.src, rel.n_dst, rel.n_src)
+        x = X[can[0]]
+        assert torch.allclose(rel.csr.spmm(x), rebuilt.spmm(x), atol=1e-5)
+        w = torch.randn(rel.n_dst, 8)
+        assert torch.allclose(rel.csr.spmm_t(w), rebuilt.spmm_t(w), atol=1e-5)
+    fused_child, fused_parent = child.fused_relations("disease"), enc.fused_relations("disease")
+    assert fused_child[0].indptr is fused_parent[0].indptr and fused_child[0].vals is not None
+    # dropout of a dropout falls back to materialised lists
+    grand = G.random_edge_dropout(child, 0.5)
+    assert not isinstance(grand["0"], G.DroppedRelation) and grand["0"].number_of_edges() == max(1, int(child["0"].number_of_edges() * 0.5))
+    # sparse adjacency
+    f = C.load("fgcn_both")
+    nd = int(f["n_drug"])
+    adj = C.sparse(f, "adj_d", nd, nd, CPU)
+    dropped = G.random_edge_dropout_sparse(adj, 0.25)
+    x = torch.randn(nd, 6)
+    view = L.adjacency_csr(dropped)
+    assert view.indptr is L.adjacency_csr(adj).indptr
+    assert torch.allclose(view.spmm(x), torch.spmm(dropped, x), atol=1e-6)
+    assert torch.allclose(view.spmm_t(x), torch.spmm(dropped.t(), x), atol=1e-6)
