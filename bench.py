@@ -284,11 +284,19 @@ def main():
         del ops
         torch.cuda.empty_cache()
         alt = "nodes" if args.scale == "edges" else "edges"
-        ops2, _, (nd2, ns2, E2, k2) = build_ops(rank, world, dev, alt)
-        steps2 = max(3, args.steps // 4)
-        el2, edges2 = measure(ops2, steps2, min(2, args.warmup))
-        other = {"scale": alt, "workload": "bipartite %dx%d, %d edges + kNN-%d" % (nd2, ns2, E2, k2),
-                 "value": edges2 * steps2 / el2, "unit": "edges/s", "ms_per_step": el2 / steps2 * 1e3, "steps": steps2}
+        ops2 = None
+        try:  # a rank that cannot build its shards must not leave the others inside a collective
+            ops2, _, (nd2, ns2, E2, k2) = build_ops(rank, world, dev, alt)
+        except Exception as exc:  # noqa: BLE001
+            sys.stderr.write("rank %d: %s-scaled variant not built: %r\n" % (rank, alt, exc))
+        ok = torch.tensor([1.0 if ops2 is not None else 0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) > 0:
+            steps2 = max(3, args.steps // 4)
+            el2, edges2 = measure(ops2, steps2, min(2, args.warmup))
+            other = {"scale": alt, "workload": "bipartite %dx%d, %d edges + kNN-%d" % (nd2, ns2, E2, k2),
+                     "value": edges2 * steps2 / el2, "unit": "edges/s", "ms_per_step": el2 / steps2 * 1e3,
+                     "steps": steps2}
         ops = [first_op]
         del ops2
 
