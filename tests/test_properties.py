@@ -1,0 +1,129 @@
+"""Property-based checks (hypothesis) of the oracle and the host-side logic on the build box:
+the oracle against independent implementations (numpy stable argsort, scipy CSR @ dense,
+sklearn's curve areas), and structural invariants of the helpers the GPU path relies on."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+from hypothesis import given, settings, strategies as st
+
+SET = settings(max_examples=40, deadline=None)
+
+
+@st.composite
+def coo(draw, max_rows=40, max_cols=30, max_edges=300):
+    n_rows = draw(st.integers(1, max_rows))
+    n_cols = draw(st.integers(1, max_cols))
+    E = draw(st.integers(0, max_edges))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, n_rows, E).astype(np.int32), rng.integers(0, n_cols, E).astype(np.int32), n_rows, n_cols, rng
+
+
+@SET
+@given(coo())
+def test_oracle_csr_is_numpy_stable_argsort(oracle, g):
+    row, col, n_rows, _, _ = g
+    indptr, indices, eid = oracle.csr_from_coo(row, col, n_rows)
+    order = np.argsort(row, kind="stable")
+    assert np.array_equal(eid, order) and np.array_equal(indices, col[order])
+    assert np.array_equal(np.diff(indptr), np.bincount(row, minlength=n_rows)) and indptr[0] == 0
+
+
+@SET
+@given(coo(), st.integers(1, 9))
+def test_oracle_sliced_csr_groups_by_slice_then_row(oracle, g, n_slices):
+    row, col, n_rows, n_cols, _ = g
+    segptr, indices, eid = oracle.csr_sliced_from_coo(row, col, n_rows, n_cols, n_slices)
+    width = max(1, -(-n_cols // n_slices))
+    assert segptr[0] == 0 and segptr[-1] == row.size and np.all(np.diff(segptr) >= 0)
+    for s_ in range(n_slices):
+        for r in range(n_rows):
+            seg = eid[segptr[s_ * n_rows + r]:segptr[s_ * n_rows + r + 1]]
+            assert np.all(row[seg] == r) and np.all(np.minimum(col[seg] // width, n_slices - 1) == s_)
+            assert np.all(np.diff(seg) > 0)  # input order kept inside a segment
+    assert np.array_equal(indices, col[eid])
+
+
+@SET
+@given(coo(), st.integers(1, 20), st.booleans(), st.booleans())
+def test_oracle_spmm_is_scipy_csr_matmul(oracle, g, F, weighted, scaled):
+    row, col, n_rows, n_cols, rng = g
+    X = rng.standard_normal((n_cols, F)).astype(np.float32)
+    vals = rng.standard_normal(row.size).astype(np.float32) if weighted else None
+    ss = rng.uniform(0.5, 1.5, n_cols).astype(np.float32) if scaled else None
+    ds = rng.uniform(0.5, 1.5, n_rows).astype(np.float32) if scaled else None
+    indptr, indices, eid = oracle.csr_from_coo(row, col, n_rows)
+    y = oracle.spmm_csr(indptr, indices, None if vals is None else vals[eid], X, ss, ds, acc="f64")
+    A = sp.coo_matrix((np.ones(row.size) if vals is None else vals.astype(np.float64), (row, col)), shape=(n_rows, n_cols)).tocsr()
+    ref = A @ (X.astype(np.float64) * (1.0 if ss is None else ss[:, None].astype(np.float64)))
+    if ds is not None:
+        ref = ref * ds[:, None].astype(np.float64)
+    assert np.allclose(y, ref, rtol=1e-9, atol=1e-9)
+    y32 = oracle.spmm_csr(indptr, indices, None if vals is None else vals[eid], X, ss, ds)
+    yabs = oracle.spmm_csr(indptr, indices, None if vals is None else vals[eid], X, ss, ds, acc="abs")
+    assert np.all(np.abs(y32 - y) <= 1e-5 * yabs + 1e-12)
+
+
+@SET
+@given(st.lists(st.integers(0, 50), min_size=1, max_size=200), st.integers(1, 8))
+def test_balanced_row_bounds_cover_and_balance(deg, parts):
+    from dream_gnn_amd.shard import balanced_row_bounds
+
+    d = torch.tensor(deg, dtype=torch.int64)
+    b = balanced_row_bounds(d, parts).tolist()
+    assert len(b) == parts + 1 and b[0] == 0 and b[-1] == len(deg) and b == sorted(b)
+    total, big = sum(deg), max(deg)
+    loads = [sum(deg[b[i]:b[i + 1]]) for i in range(parts)]
+    assert sum(loads) == total and max(loads) <= total / parts + big  # within one row of the ideal
+
+
+@SET
+@given(st.integers(3, 200), st.integers(0, 2 ** 31 - 1))
+def test_metric_areas_equal_sklearn(n, seed):
+    from sklearn import metrics
+
+    from dream_gnn_amd.harness import auroc_aupr
+
+    rng = np.random.default_rng(seed)
+    y = (rng.random(n) < 0.3).astype(np.float64)
+    y[0], y[1] = 0.0, 1.0
+    score = np.round(rng.standard_normal(n) + y, rng.integers(0, 4))  # rounding creates ties
+    auroc, aupr = auroc_aupr(y, score)
+    fpr, tpr, _ = metrics.roc_curve(y, score)
+    prec, rec, _ = metrics.precision_recall_curve(y, score)
+    assert abs(auroc - metrics.auc(fpr, tpr)) < 1e-12 and abs(aupr - metrics.auc(rec, prec)) < 1e-12
+
+
+@settings(max_examples=15, deadline=None)
+@given(st.integers(4, 40), st.integers(1, 6), st.integers(0, 2 ** 31 - 1), st.booleans())
+def test_similarity_graph_builder_equals_oracle_pipeline(oracle, n, k, seed, symm):
+    from dream_gnn_amd import graph as G
+
+    rng = np.random.default_rng(seed)
+    A = rng.random((n, n))
+    sim = (A + A.T) / 2  # distinct values almost surely: no top-k ties
+    np.fill_diagonal(sim, 1.0)
+    r, c, v, _ = oracle.similarity_graph_coo(sim, k, symm)
+    adj = G.similarity_graph(torch.from_numpy(sim), k, symm).coalesce()
+    assert np.array_equal(adj.indices()[0].numpy(), r) and np.array_equal(adj.indices()[1].numpy(), c)
+    assert np.array_equal(adj.values().numpy(), v)
+
+
+@SET
+@given(st.integers(1, 300), st.floats(0.0, 0.95), st.integers(0, 2 ** 31 - 1))
+def test_edge_dropout_keep_count_and_subset(E, rate, seed):
+    """augmentation.py:48-52: keep max(1, int(E * (1 - p))) edges, a subset without repetition."""
+    from dream_gnn_amd import graph as G
+
+    gen = torch.Generator().manual_seed(seed)
+    src = torch.arange(E) % 7
+    dst = torch.arange(E) % 5
+    hg = G.HeteroGraph({("drug", "0", "disease"): (src, dst)}, {"drug": 7, "disease": 5})
+    child = G.random_edge_dropout(hg, rate, gen)["0"]
+    keep = max(1, int(E * (1 - rate)))
+    assert child.number_of_edges() == keep and child.src.shape[0] == keep
+    idx = child.keep_idx.tolist()
+    assert len(set(idx)) == keep and all(0 <= i < E for i in idx)
+    assert torch.equal(child.src, src[child.keep_idx]) and torch.equal(child.dst, dst[child.keep_idx])
+    assert float(child.keep_mask().sum()) == keep
