@@ -18,7 +18,7 @@ from __future__ import annotations
 import math
 import warnings
 import weakref
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 import torch.nn as nn

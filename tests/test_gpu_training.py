@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _problem(dev, nd=151, ns=113, emb=48):
-    from dream_gnn_amd import graph as G, synth
+    from dream_gnn_amd import graph as G
 
     rng = np.random.default_rng(5)
     pairs = np.array([(d, s) for d in range(nd) for s in range(ns)])

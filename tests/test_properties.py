@@ -2,7 +2,6 @@
 the oracle against independent implementations (numpy stable argsort, scipy CSR @ dense,
 sklearn's curve areas), and structural invariants of the helpers the GPU path relies on."""
 import numpy as np
-import pytest
 import scipy.sparse as sp
 import torch
 from hypothesis import given, settings, strategies as st
