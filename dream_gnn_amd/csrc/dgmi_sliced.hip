@@ -156,26 +156,52 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
   }
 }
 
-template <bool HAS_DS>
+// Y[row] = dst_scale[row] * (plane_0[row] + plane_1[row] + ...) in slice order; one float4 per
+// thread, all S plane loads of an element in flight together (S known at compile time for the
+// usual 8 slices).  dst_scale and Y already point at the chunk's first row.
+template <bool HAS_DS, int S>
 __global__ __launch_bounds__(256) void reduce_planes_kernel(const float* __restrict__ planes, int64_t ldp,
                                                             int64_t rows, int F4, int n_slices,
                                                             const float* __restrict__ dst_scale,
                                                             float* __restrict__ Y, int64_t ldy) {
-  // dst_scale and Y already point at the chunk's first row
   const int64_t total = rows * F4;
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t plane_stride = rows * ldp;
+  const bool dense = (ldp == 4 * (int64_t)F4) && (ldy == ldp);  // element t of a plane is at offset 4t
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
-    const int64_t row = t / F4;
-    const int c = (int)(t - row * F4) * 4;
-    const float* p = planes + row * ldp + c;
-    float4 acc = *reinterpret_cast<const float4*>(p);
-    for (int s = 1; s < n_slices; ++s) {
-      const float4 v = *reinterpret_cast<const float4*>(p + s * plane_stride);
-      acc.x += v.x;
-      acc.y += v.y;
-      acc.z += v.z;
-      acc.w += v.w;
+    int64_t row, poff, yoff;
+    if (dense) {
+      row = t / F4;
+      poff = yoff = 4 * t;
+    } else {
+      row = t / F4;
+      const int c = (int)(t - row * F4) * 4;
+      poff = row * ldp + c;
+      yoff = row * ldy + c;
+    }
+    const float* p = planes + poff;
+    float4 acc;
+    if (S > 0) {
+      float4 v[S > 0 ? S : 1];
+#pragma unroll
+      for (int s = 0; s < S; ++s) v[s] = *reinterpret_cast<const float4*>(p + s * plane_stride);
+      acc = v[0];
+#pragma unroll
+      for (int s = 1; s < S; ++s) {
+        acc.x += v[s].x;
+        acc.y += v[s].y;
+        acc.z += v[s].z;
+        acc.w += v[s].w;
+      }
+    } else {
+      acc = *reinterpret_cast<const float4*>(p);
+      for (int s = 1; s < n_slices; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(p + s * plane_stride);
+        acc.x += v.x;
+        acc.y += v.y;
+        acc.z += v.z;
+        acc.w += v.w;
+      }
     }
     if (HAS_DS) {
       const float d = dst_scale[row];
@@ -184,7 +210,7 @@ __global__ __launch_bounds__(256) void reduce_planes_kernel(const float* __restr
       acc.z *= d;
       acc.w *= d;
     }
-    *reinterpret_cast<float4*>(Y + row * ldy + c) = acc;
+    *reinterpret_cast<float4*>(Y + yoff) = acc;
   }
 }
 
@@ -232,12 +258,15 @@ hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s) {
     if (blocks > 8192) blocks = 8192;
     const float* ds = a.dst_scale ? a.dst_scale + r0 : nullptr;
     float* y = a.Y + r0 * a.ldy;
-    if (ds)
-      hipLaunchKernelGGL(reduce_planes_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a.planes, a.ldp,
-                         r1 - r0, F4, (int)a.n_slices, ds, y, a.ldy);
-    else
-      hipLaunchKernelGGL(reduce_planes_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a.planes, a.ldp,
-                         r1 - r0, F4, (int)a.n_slices, ds, y, a.ldy);
+#define DGMI_REDUCE(D, S)                                                                               \
+  hipLaunchKernelGGL((reduce_planes_kernel<D, S>), dim3((unsigned)blocks), dim3(256), 0, s, a.planes, a.ldp, \
+                     r1 - r0, F4, (int)a.n_slices, ds, y, a.ldy)
+    if (a.n_slices == 8) {
+      if (ds) DGMI_REDUCE(true, 8); else DGMI_REDUCE(false, 8);
+    } else {
+      if (ds) DGMI_REDUCE(true, 0); else DGMI_REDUCE(false, 0);
+    }
+#undef DGMI_REDUCE
     err = hipGetLastError();
     if (err != hipSuccess) return err;
   }

@@ -283,6 +283,7 @@ class SlicedCSR:
 # Measured on MI355X (tools/explore.py slicedcap, 10 M edges, F=128): sliced/planned time ratio
 # 1.0 at a 6 MB table, 1.9-2.4x at 13-51 MB, 1.2x at 102 MB, 1.0 at 205 MB; 1.55x at average
 # degree 100, 0.72x at 25 (a (row, slice) segment of 3 edges is all overhead).
+FORCE_KERNEL = {"planned": "planned", "sliced": "sliced"}.get(__import__("os").environ.get("DGMI_FORCE_KERNEL", ""))
 SLICED_MIN_TABLE_BYTES = 10 << 20
 SLICED_MAX_TABLE_BYTES = 160 << 20
 SLICED_MIN_AVG_DEGREE = 64
@@ -406,6 +407,8 @@ class CSRGraph:
         S.regular = self._is_regular(max_deg, self.nnz, S.n_dst)
 
     def _use_sliced(self, F: int, n_rows: int, n_cols: int, regular: bool) -> bool:
+        if FORCE_KERNEL is not None:  # debugging / A-B aid: DGMI_FORCE_KERNEL=planned|sliced
+            return FORCE_KERNEL == "sliced" and F % 4 == 0 and n_rows * SlicedCSR.N_SLICES < 2 ** 31 - 1
         table = n_cols * F * 4
         return (bool(regular) and F % 4 == 0 and SLICED_MIN_TABLE_BYTES <= table <= SLICED_MAX_TABLE_BYTES
                 and self.nnz >= SLICED_MIN_AVG_DEGREE * n_rows and n_rows * SlicedCSR.N_SLICES < 2 ** 31 - 1)
