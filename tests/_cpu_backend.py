@@ -58,7 +58,7 @@ def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan,
 def patched():
     from dream_gnn_amd import ops
 
-    names = ("csr_from_coo", "gather_f32", "spmm_csr_raw", "_launch_spmm", "_require_device", "build_plan",
+    names = ("csr_from_coo", "gather_f32", "spmm_csr_raw", "_launch_spmm", "_require_device", "build_plan", "FORCE_KERNEL",
              "gather_concat_raw", "gather_add_raw")
     saved = {k: getattr(ops, k) for k in names}
     ops.csr_from_coo, ops.gather_f32, ops.spmm_csr_raw = csr_from_coo, gather_f32, spmm_csr_raw
@@ -67,6 +67,7 @@ def patched():
     ops.gather_add_raw = gather_add_raw
     ops._require_device = lambda *ts: next((t.device for t in ts if t is not None), None)
     ops.build_plan = lambda indptr, nnz, chunk=None: None  # launch plans are a device-side concern
+    ops.FORCE_KERNEL = "planned"  # the sliced layout is a device-side concern too
     try:
         yield
     finally:

@@ -56,6 +56,7 @@ def test_csr_build_is_a_stable_sort_at_full_size(cfg4):
     assert torch.equal(eid2.long(), torch.arange(E, device=eid.device))
 
 
+@pytest.mark.skipif(bool(__import__("os").environ.get("DGMI_FORCE_KERNEL")), reason="kernel choice is forced")
 def test_spmm_full_size_properties(oracle, cfg4, dev):
     from dream_gnn_amd import ops, synth
 

@@ -276,6 +276,7 @@ def test_xcd_sliced_edge_cases(oracle, dev):
     assert np.abs(y - y64).max() <= 1e-5 * np.abs(y64).max()
 
 
+@pytest.mark.skipif(bool(__import__("os").environ.get("DGMI_FORCE_KERNEL")), reason="kernel choice is forced")
 def test_csrgraph_picks_sliced_only_when_profitable(dev):
     from dream_gnn_amd import ops
 
