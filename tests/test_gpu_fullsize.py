@@ -178,3 +178,49 @@ def test_edge_dropout_rebuild_full_size(cfg4, dev):
     a = torch.sort(dropped["0"].src.long() * NS + dropped["0"].dst.long())[0]
     b = torch.sort(dropped["rev-0"].dst.long() * NS + dropped["rev-0"].src.long())[0]
     assert not torch.equal(a, b)
+
+
+def test_addresses_beyond_4_gib(oracle, dev):
+    """Feature tables and edge outputs larger than 2^32 bytes: every kernel must do its row
+    addressing in 64 bits.  9 M x 128 fp32 sources (4.6 GB) with all edges pointing into the top
+    of the table; a 5.1 GB gather-concat output."""
+    from dream_gnn_amd import ops
+
+    gen = torch.Generator(device=dev).manual_seed(5)
+    n_src, n_dst, E, Fw = 9_000_000, 2_000, 200_000, 128
+    X = torch.empty(n_src, Fw, device=dev)
+    X[-600_000:] = torch.randn(600_000, Fw, generator=gen, device=dev)  # only the part that is read needs data
+    src = (n_src - 1 - torch.randint(0, 600_000, (E,), generator=gen, device=dev)).to(torch.int32)
+    dst = torch.randint(0, n_dst, (E,), generator=gen, device=dev, dtype=torch.int32)
+    vals = torch.rand(E, generator=gen, device=dev)
+    g = ops.CSRGraph(dst, src, n_dst, n_src, vals=vals)
+    ref = torch.zeros(n_dst, Fw, device=dev, dtype=torch.float64).index_add_(
+        0, dst.long(), X.index_select(0, src.long()).double() * vals.double()[:, None])
+    for y in (ops.spmm_csr_raw(g.indptr, g.indices, g.vals, X),            # a wave per row
+              ops.spmm_csr_raw(g.indptr, g.indices, g.vals, X, plan=g.plan),  # planned
+              ops.SlicedCSR(dst, src, n_dst, n_src, vals=vals).spmm(X)):      # XCD-sliced
+        assert float((y.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # transpose product writes rows beyond the 4 GiB mark of a 9 M-row output
+    W = torch.randn(n_dst, Fw, generator=gen, device=dev)
+    dx = g.spmm_t(W)
+    rows = src[:200].long()
+    it, ix, vt, _ = g.transposed()
+    for r in rows[:20].tolist():
+        lo, hi = int(it[r]), int(it[r + 1])
+        want = (W.index_select(0, ix[lo:hi].long()).double() * vt[lo:hi].double()[:, None]).sum(0)
+        assert float((dx[r].double() - want).abs().max()) <= 1e-5 * float(want.abs().max() + 1e-30)
+    del X, dx, g
+    torch.cuda.empty_cache()
+    # gather-concat with a > 4 GiB output
+    Ea, n_a, n_b = 5_000_000, 1000, 700
+    A, B = torch.randn(n_a, 128, device=dev), torch.randn(n_b, 128, device=dev)
+    s = torch.randint(0, n_a, (Ea,), generator=gen, device=dev, dtype=torch.int32)
+    d = torch.randint(0, n_b, (Ea,), generator=gen, device=dev, dtype=torch.int32)
+    out = ops.gather_concat_raw(s, d, A, B)
+    assert out.numel() * 4 > 2 ** 32
+    for e in (0, 1, Ea // 2, Ea - 2, Ea - 1):
+        assert torch.equal(out[e, :128], A[int(s[e])]) and torch.equal(out[e, 128:], B[int(d[e])])
+    tail = slice(Ea - 4096, Ea)
+    assert torch.equal(out[tail], torch.cat([A[s[tail].long()], B[d[tail].long()]], 1))
+    ga = ops.gather_add_raw(s, d, A, B)
+    assert torch.equal(ga[tail], A[s[tail].long()] + B[d[tail].long()])
