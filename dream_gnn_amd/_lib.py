@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- must come first: libdgmi.so binds to the HIP runt
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgmi.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # name -> (restype, argtypes); mirrors include/dgmi.h one to one.
 _vp = ctypes.c_void_p
@@ -33,6 +33,8 @@ SIGNATURES = {
     "dgmi_spmm_sliced_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                             ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
     "dgmi_gather_add_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "dgmi_random_subset_workspace_bytes": (ctypes.c_size_t, []),
+    "dgmi_random_subset_mask_f32": (ctypes.c_int, [_i64, _i64, ctypes.c_uint64, _vp, _vp, ctypes.c_size_t, _vp]),
     "dgmi_spmm_default_chunk": (ctypes.c_int32, [_i64, _i64]),
     "dgmi_spmm_plan_bytes": (ctypes.c_size_t, [_i64, _i64, ctypes.c_int32]),
     "dgmi_spmm_partials_bytes": (ctypes.c_size_t, [_i64, ctypes.c_int32, _i64]),

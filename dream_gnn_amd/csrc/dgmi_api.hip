@@ -245,6 +245,18 @@ DGMI_API int dgmi_gather_add_f32(const int32_t* src, const int32_t* dst, int64_t
   return from_hip(dgmi::gather_add_f32(src, dst, E, A, lda, B, ldb, bias, F, out, ldo, as_stream(stream)));
 }
 
+DGMI_API size_t dgmi_random_subset_workspace_bytes(void) { return dgmi::random_subset_workspace_bytes(); }
+
+DGMI_API int dgmi_random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask, void* workspace,
+                                         size_t workspace_bytes, dgmi_stream_t stream) {
+  if (E < 0 || keep < 0 || keep > E) return DGMI_ERR_INVALID_ARG;
+  if (E > INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (E == 0) return DGMI_OK;
+  if (mask == nullptr || workspace == nullptr) return DGMI_ERR_INVALID_ARG;
+  if (workspace_bytes < dgmi::random_subset_workspace_bytes()) return DGMI_ERR_WORKSPACE;
+  return from_hip(dgmi::random_subset_mask_f32(E, keep, seed, mask, workspace, as_stream(stream)));
+}
+
 DGMI_API int dgmi_gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,
                     dgmi_stream_t stream) {
   if (n < 0) return DGMI_ERR_INVALID_ARG;

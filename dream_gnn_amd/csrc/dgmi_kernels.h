@@ -102,6 +102,11 @@ hipError_t gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, con
                           const float* B, int64_t ldb, const float* bias, int64_t F, float* out,
                           int64_t ldo, hipStream_t s);
 
+// mask[e] = 1 for a uniformly random subset of exactly `keep` of the E edges (dgmi_select.hip)
+size_t random_subset_workspace_bytes();
+hipError_t random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask, void* workspace,
+                                  hipStream_t s);
+
 hipError_t gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,
                       hipStream_t s);
 

@@ -97,20 +97,23 @@ class RelationGraph:
 
 
 class DroppedRelation(RelationGraph):
-    """A relation after edge dropout (augmentation.py:13-89), kept as *parent relation + kept edge
-    positions* instead of a re-sorted copy.
+    """A relation after edge dropout (augmentation.py:13-89), kept as *parent relation + which
+    edges survive* instead of a re-sorted copy.
 
-    The kept edge list (``src`` / ``dst``, in the order of the random permutation prefix, as the
-    reference builds it) is materialised only if somebody asks for it.  ``csr`` is a value view of
-    the parent's CSR with a 0/1 keep mask as edge values: no sort, no plan rebuild, no host sync —
-    the per-iteration graph churn of train.py:267 becomes one ``randperm`` and a few gathers.
-    Dropped edges contribute ``0 * x`` to the sums (identical to removing them for finite x).
+    ``csr`` is a value view of the parent's CSR with a 0/1 keep mask as edge values: no sort, no
+    plan rebuild, no host sync — the per-iteration graph churn of train.py:267 becomes one subset
+    selection and a few gathers.  The kept edge list (``src`` / ``dst``) is materialised only if
+    somebody asks for it (in permutation order when the subset came from ``randperm``, as the
+    reference builds it; in ascending order otherwise).  Dropped edges contribute ``0 * x`` to the
+    sums (identical to removing them for finite x).
     """
 
-    def __init__(self, parent: RelationGraph, keep_idx: torch.Tensor, srcdata: dict, dstdata: dict):
+    def __init__(self, parent: RelationGraph, n_keep: int, srcdata: dict, dstdata: dict,
+                 keep_idx: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None):
         self.canonical = parent.canonical
         self.parent = parent
-        self.keep_idx = keep_idx
+        self.n_keep = int(n_keep)
+        self._keep_idx, self._mask = keep_idx, mask
         self.n_src, self.n_dst = parent.n_src, parent.n_dst
         self.srcdata, self.dstdata = srcdata, dstdata
         self._csr = None
@@ -118,6 +121,20 @@ class DroppedRelation(RelationGraph):
         self._lists = None
         self.trusted = True
         self.regular_hint = None
+
+    @property
+    def keep_idx(self) -> torch.Tensor:
+        """Positions of the kept edges in the parent's edge list."""
+        if self._keep_idx is None:
+            self._keep_idx = torch.nonzero(self._mask, as_tuple=True)[0]  # host sync: only on demand
+        return self._keep_idx
+
+    def keep_mask(self) -> torch.Tensor:
+        """float 0/1 over the parent's edges."""
+        if self._mask is None:
+            m = torch.zeros(self.parent.number_of_edges(), dtype=torch.float32, device=self._keep_idx.device)
+            self._mask = m.index_fill_(0, self._keep_idx, 1.0)  # (m[idx] = 1.0 would synchronise with the host)
+        return self._mask
 
     def _materialise(self):
         if self._lists is None:
@@ -133,16 +150,11 @@ class DroppedRelation(RelationGraph):
         self._lists = tuple(lists)
 
     def number_of_edges(self) -> int:
-        return int(self.keep_idx.shape[0])
+        return self.n_keep
 
     @property
     def device(self):
-        return self.keep_idx.device
-
-    def keep_mask(self) -> torch.Tensor:
-        """float 0/1 over the parent's edges."""
-        m = torch.zeros(self.parent.number_of_edges(), dtype=torch.float32, device=self.keep_idx.device)
-        return m.index_fill_(0, self.keep_idx, 1.0)  # (m[idx] = 1.0 would synchronise with the host)
+        return self.parent.device
 
     @property
     def csr(self) -> ops.CSRGraph:
@@ -399,14 +411,38 @@ def from_dgl(g) -> HeteroGraph:
     return out
 
 
+def _draw_seed(generator: Optional[torch.Generator]) -> Optional[int]:
+    """A 62-bit seed from a CPU generator (or torch's default CPU RNG) without touching the GPU;
+    None when the caller handed in a device generator (the randperm path is used then)."""
+    if generator is not None and generator.device.type != "cpu":
+        return None
+    return int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())
+
+
+def _select_kept(E: int, keep: int, device, generator, selection: Optional[str]):
+    """(keep_idx or None, mask or None) for a uniformly random subset of exactly ``keep`` edges.
+
+    ``"select"`` (default on the GPU): ``dgmi_random_subset_mask_f32`` — radix select on per-edge
+    hash keys, no permutation is materialised.  ``"randperm"``: the reference's literal procedure,
+    ``torch.randperm(E)[:keep]`` (augmentation.py:51-52)."""
+    if selection is None:
+        selection = "select" if torch.device(device).type == "cuda" else "randperm"
+    if selection == "select":
+        seed = _draw_seed(generator)
+        if seed is not None:
+            return None, ops.random_subset_mask(E, keep, seed, device)
+    return torch.randperm(E, device=device, generator=generator)[:keep], None
+
+
 def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
-                        generator: Optional[torch.Generator] = None) -> HeteroGraph:
+                        generator: Optional[torch.Generator] = None,
+                        selection: Optional[str] = None) -> HeteroGraph:
     """Edge dropout on the encoder graph — augmentation.py:13-89.
 
-    Per edge type independently, keep the first ``max(1, int(E*(1-p)))`` entries of a random
-    permutation (so ``rev-r`` stops being the transpose of ``r``); node data is *copied, not
-    recomputed* (augmentation.py:68-70), so ``ci``/``cj`` go stale exactly as in the reference.
-    The result holds, per relation, the parent relation and the kept positions
+    Per edge type independently, keep a uniformly random subset of ``max(1, int(E*(1-p)))`` edges
+    (so ``rev-r`` stops being the transpose of ``r``); node data is *copied, not recomputed*
+    (augmentation.py:68-70), so ``ci``/``cj`` go stale exactly as in the reference.
+    The result holds, per relation, the parent relation and the surviving subset
     (:class:`DroppedRelation`): its products run on the parent's CSRs with a keep mask as edge
     values — nothing is re-sorted and nothing synchronises with the host.
     """
@@ -429,8 +465,8 @@ def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
             out._rels[can] = child
             continue
         keep = max(1, int(E * (1 - dropout_rate)))
-        perm = torch.randperm(E, device=rel.device, generator=generator)[:keep]
-        out._rels[can] = DroppedRelation(rel, perm, out._ndata[st], out._ndata[dt])
+        keep_idx, mask = _select_kept(E, keep, rel.device, generator, selection)
+        out._rels[can] = DroppedRelation(rel, keep, out._ndata[st], out._ndata[dt], keep_idx=keep_idx, mask=mask)
     if not nested:
         out.__dict__["_dropout_parent"] = graph
     for nt in graph.ntypes:
@@ -439,10 +475,26 @@ def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
     return out
 
 
-def random_edge_dropout_sparse(adj: torch.Tensor, dropout_rate: float = 0.1,
-                               generator: Optional[torch.Generator] = None) -> torch.Tensor:
-    """Edge dropout on a sparse COO adjacency — augmentation.py:92-124 (uncoalesced result,
-    random entry order)."""
+def random_edge_dropout_sparse(adj, dropout_rate: float = 0.1, generator: Optional[torch.Generator] = None,
+                               as_view: bool = False, selection: Optional[str] = None):
+    """Edge dropout on a sparse COO adjacency — augmentation.py:92-124.
+
+    Default: a new (uncoalesced, randomly ordered) sparse COO tensor, as the reference returns;
+    ``layers.adjacency_csr`` recognises it and applies the dropout as a keep mask over the parent's
+    CSR instead of re-sorting its entries.  ``as_view=True`` skips the tensor altogether and returns
+    that masked ``CSRGraph`` view directly (``GraphConvolution.forward`` accepts it): no entry is
+    copied and nothing synchronises.
+    """
+    if as_view:
+        from .layers import adjacency_csr  # local import: layers imports this module
+
+        base = adjacency_csr(adj)
+        E = base.nnz
+        keep = max(1, int(E * (1 - dropout_rate)))
+        keep_idx, mask = _select_kept(E, keep, base.device, generator, selection)
+        if mask is None:
+            mask = torch.zeros(E, dtype=torch.float32, device=base.device).index_fill_(0, keep_idx, 1.0)
+        return base.masked(mask)
     idx, val = adj._indices(), adj._values()
     E = val.shape[0]
     keep = max(1, int(E * (1 - dropout_rate)))

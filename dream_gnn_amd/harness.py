@@ -31,7 +31,9 @@ def augment(batch: Dict, edge_dropout_rate: float = 0.1, feature_noise_scale: fl
     out["enc_graph"] = G.random_edge_dropout(batch["enc_graph"], edge_dropout_rate, generator)
     for k in ("drug_graph", "disease_graph", "drug_feature_graph", "disease_feature_graph"):
         if batch.get(k) is not None:
-            out[k] = G.random_edge_dropout_sparse(batch[k], edge_dropout_rate, generator)
+            # a masked view of the cached CSR (GraphConvolution accepts it); the reference's sparse
+            # tensor is available with as_view=False
+            out[k] = G.random_edge_dropout_sparse(batch[k], edge_dropout_rate, generator, as_view=True)
     for k, scale in (("drug_feat", feature_noise_scale), ("disease_feat", feature_noise_scale),
                      ("drug_sim_feat", sim_noise_scale), ("disease_sim_feat", sim_noise_scale)):
         if batch.get(k) is not None:

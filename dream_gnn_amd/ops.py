@@ -620,3 +620,21 @@ class _GatherAdd(torch.autograd.Function):
 def gather_add(pairs: EdgePairs, A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None):
     """Differentiable ``A[src] + B[dst] (+ bias)`` over the decoder edges."""
     return _GatherAdd.apply(A, B, bias, pairs)
+
+
+# ---------------------------------------------------------------------------------------------
+# (D3) edge-dropout selection — augmentation.py:48-52, 114-118
+# ---------------------------------------------------------------------------------------------
+def random_subset_mask(E: int, keep: int, seed: int, device) -> torch.Tensor:
+    """float 0/1 mask over E edges with exactly ``keep`` ones, a uniformly random subset that is a
+    deterministic function of ``(seed, E, keep)`` (``dgmi_random_subset_mask_f32``)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("dream_gnn_amd ops run on the MI355X only: got device %s" % device)
+    mask = torch.empty(E, dtype=torch.float32, device=device)
+    nbytes = int(_L.dgmi_random_subset_workspace_bytes())
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    with _guard(device):
+        _lib.check(_L.dgmi_random_subset_mask_f32(E, keep, seed & 0xFFFFFFFFFFFFFFFF, _ptr(mask), _ptr(ws), nbytes,
+                                                  _stream(device)), "dgmi_random_subset_mask_f32")
+    return mask

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 6
+#define DGMI_ABI_VERSION 7
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -214,6 +214,19 @@ DGMI_API int dgmi_gather_concat_f32(const int32_t* src, const int32_t* dst, int6
 DGMI_API int dgmi_gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
                                  int64_t lda, const float* B, int64_t ldb, const float* bias,
                                  int64_t F, float* out, int64_t ldo, dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
+ * (D3) Edge dropout selection: mask[e] = 1.0f for a uniformly random subset of exactly `keep`
+ * of the E edges, 0.0f elsewhere — what `perm = randperm(E); keep = perm[:num_keep]`
+ * (augmentation.py:48-52, 114-118) selects, without materialising the permutation: per-edge
+ * keys (hash32(seed, e), e), 4-pass radix select of the keep-th smallest, one mask pass.
+ * Deterministic in (seed, E, keep).  workspace: dgmi_random_subset_workspace_bytes() bytes.
+ * 0 <= keep <= E.
+ */
+DGMI_API size_t dgmi_random_subset_workspace_bytes(void);
+DGMI_API int dgmi_random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask,
+                                         void* workspace, size_t workspace_bytes,
+                                         dgmi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -239,6 +239,23 @@ def similarity_graph_coo(sim, k, symm=True):
     return norm.row.astype(np.int64), norm.col.astype(np.int64), norm.data.astype(np.float32), n
 
 
+def random_subset_mask(E, keep, seed):
+    """Restatement of ``dgmi_random_subset_mask_f32``: keys (hash32(seed, e), e) with the
+    splitmix64 finaliser; the ``keep`` smallest keys are kept.  The subset it stands for is the
+    reference's ``randperm(E)[:num_keep]`` (augmentation.py:48-52): uniformly random, exact size."""
+    with np.errstate(over="ignore"):
+        e = np.arange(E, dtype=np.uint64)
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + (e + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    h = (z >> np.uint64(32)).astype(np.uint64)
+    order = np.lexsort((np.arange(E), h))  # by hash, ties by edge id
+    mask = np.zeros(E, np.float32)
+    mask[order[:keep]] = 1.0
+    return mask
+
+
 def edge_dropout_keep(num_edges, dropout_rate, perm):
     """Kept edge positions of random_edge_dropout(_sparse): the first
     max(1, int(E*(1-p))) entries of a permutation (augmentation.py:48-52,114-118)."""

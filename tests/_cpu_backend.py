@@ -50,6 +50,10 @@ def gather_add_raw(src, dst, A, B, bias=None, out=None):
     return y
 
 
+def random_subset_mask(E, keep, seed, device):
+    return torch.from_numpy(O.random_subset_mask(E, keep, seed))
+
+
 def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx):
     return spmm_csr_raw(indptr, indices, vals, X, src_scale, dst_scale, out=out)
 
@@ -59,12 +63,13 @@ def patched():
     from dream_gnn_amd import ops
 
     names = ("csr_from_coo", "gather_f32", "spmm_csr_raw", "_launch_spmm", "_require_device", "build_plan", "FORCE_KERNEL",
-             "gather_concat_raw", "gather_add_raw")
+             "gather_concat_raw", "gather_add_raw", "random_subset_mask")
     saved = {k: getattr(ops, k) for k in names}
     ops.csr_from_coo, ops.gather_f32, ops.spmm_csr_raw = csr_from_coo, gather_f32, spmm_csr_raw
     ops._launch_spmm = _launch_spmm
     ops.gather_concat_raw = gather_concat_raw
     ops.gather_add_raw = gather_add_raw
+    ops.random_subset_mask = random_subset_mask
     ops._require_device = lambda *ts: next((t.device for t in ts if t is not None), None)
     ops.build_plan = lambda indptr, nnz, chunk=None: None  # launch plans are a device-side concern
     ops.FORCE_KERNEL = "planned"  # the sliced layout is a device-side concern too

@@ -18,7 +18,7 @@ def _declared():
 def test_header_declares_the_expected_entry_points():
     assert _declared() == ["dgmi_abi_version", "dgmi_csr_from_coo_i32", "dgmi_csr_sliced_from_coo_i32",
                            "dgmi_device_ok", "dgmi_gather_add_f32", "dgmi_gather_concat_f32",
-                           "dgmi_gather_f32",
+                           "dgmi_gather_f32", "dgmi_random_subset_mask_f32", "dgmi_random_subset_workspace_bytes",
                            "dgmi_spmm_csr_f32", "dgmi_spmm_csr_planned_f32", "dgmi_spmm_default_chunk",
                            "dgmi_spmm_partials_bytes", "dgmi_spmm_plan_build", "dgmi_spmm_plan_bytes",
                            "dgmi_spmm_sliced_f32", "dgmi_spmm_sliced_planes_bytes", "dgmi_status_string"]

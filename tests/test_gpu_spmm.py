@@ -370,3 +370,43 @@ def test_gather_add_forward_backward(oracle, dev, F):
         ref = oracle.spmm_csr(ip, ix, None, dO, acc="f64")
         assert np.abs(grad.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
     assert np.abs(c.grad.cpu().numpy() - dO.astype(np.float64).sum(0)).max() <= 1e-4 * np.abs(dO).sum(0).max()
+
+
+@pytest.mark.parametrize("E,keep", [(1, 1), (7, 3), (1000, 1), (1000, 999), (1000, 1000), (1000, 0), (123457, 111111),
+                                    (3_000_000, 2_700_000)])
+def test_random_subset_mask_bit_exact(oracle, dev, E, keep):
+    """(D3) exact-size random edge selection: integer work, bit-exact against the oracle."""
+    from dream_gnn_amd import ops
+
+    for seed in (0, 12345678901234567):
+        m = ops.random_subset_mask(E, keep, seed, dev).cpu().numpy()
+        assert m.sum() == keep
+        assert np.array_equal(m, oracle.random_subset_mask(E, keep, seed))
+
+
+def test_edge_dropout_select_path_no_sync_and_same_product(dev):
+    from dream_gnn_amd import graph as G, ops
+
+    gen = torch.Generator().manual_seed(3)
+    n_d, n_s, E = 300, 200, 20000
+    d = torch.randint(0, n_d, (E,), generator=gen).to(dev)
+    s_ = torch.randint(0, n_s, (E,), generator=gen).to(dev)
+    hg = G.HeteroGraph({("drug", "0", "disease"): (d, s_), ("disease", "rev-0", "drug"): (s_, d)},
+                       {"drug": n_d, "disease": n_s}).int()
+    hg["0"].csr, hg["rev-0"].csr  # parents validated once
+    child = G.random_edge_dropout(hg, 0.1, generator=gen)
+    rel = child["0"]
+    assert isinstance(rel, G.DroppedRelation) and rel._keep_idx is None  # select path: mask only, nothing read back
+    assert rel.number_of_edges() == int(E * 0.9) and float(rel.keep_mask().sum()) == int(E * 0.9)
+    X = torch.randn(n_d, 64, device=dev)
+    rebuilt = ops.CSRGraph(rel.dst, rel.src, rel.n_dst, rel.n_src)  # materialises the kept lists (ascending)
+    assert rel.src.shape[0] == int(E * 0.9)
+    a, b = rel.csr.spmm(X), rebuilt.spmm(X)
+    assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    # same generator state -> same subset; the literal randperm procedure is still available
+    g1, g2 = torch.Generator().manual_seed(9), torch.Generator().manual_seed(9)
+    m1 = G.random_edge_dropout(hg, 0.3, generator=g1)["0"].keep_mask()
+    m2 = G.random_edge_dropout(hg, 0.3, generator=g2)["0"].keep_mask()
+    assert torch.equal(m1, m2)
+    lit = G.random_edge_dropout(hg, 0.3, selection="randperm")["0"]
+    assert lit._keep_idx is not None and lit.number_of_edges() == int(E * 0.7)

@@ -160,7 +160,10 @@ def test_train_step_structure_on_cpu_backend():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     aug = H.augment(batch)
     assert aug["enc_graph"].number_of_edges("0") == max(1, int(batch["enc_graph"].number_of_edges("0") * 0.9))
-    assert aug["drug_graph"]._values().shape[0] == max(1, int(batch["drug_graph"]._values().shape[0] * 0.9))
+    nnz = batch["drug_graph"]._values().shape[0]  # harness.augment drops sparse adjacencies as masked CSR views
+    assert int((aug["drug_graph"].vals != 0).sum()) == max(1, int(nnz * 0.9)) and aug["drug_graph"].nnz == nnz
+    sp_drop = G.random_edge_dropout_sparse(batch["drug_graph"], 0.1)  # the reference's return type is still available
+    assert sp_drop.is_sparse and sp_drop._values().shape[0] == max(1, int(nnz * 0.9))
     assert aug["dec_graph"] is batch["dec_graph"] and not torch.equal(aug["drug_feat"], batch["drug_feat"])
     auroc, aupr = H.evaluate(net, batch, labels)
     assert 0.0 <= auroc <= 1.0 and 0.0 <= aupr <= 1.0
@@ -231,3 +234,15 @@ def test_edge_dropout_is_a_mask_view_with_the_same_product():
     assert view.indptr is L.adjacency_csr(adj).indptr
     assert torch.allclose(view.spmm(x), torch.spmm(dropped, x), atol=1e-6)
     assert torch.allclose(view.spmm_t(x), torch.spmm(dropped.t(), x), atol=1e-6)
+
+
+def test_random_subset_selection_is_exact_and_uniformish(oracle):
+    """oracle.random_subset_mask (restating dgmi_random_subset_mask_f32): exact size, deterministic
+    in the seed, different seeds differ, inclusion frequency ~ keep / E."""
+    E, keep = 5000, 1234
+    m1, m2 = oracle.random_subset_mask(E, keep, 42), oracle.random_subset_mask(E, keep, 42)
+    assert m1.sum() == keep and np.array_equal(m1, m2) and set(np.unique(m1)) <= {0.0, 1.0}
+    assert not np.array_equal(m1, oracle.random_subset_mask(E, keep, 43))
+    assert oracle.random_subset_mask(E, 0, 1).sum() == 0 and oracle.random_subset_mask(E, E, 1).sum() == E
+    freq = sum(oracle.random_subset_mask(400, 100, s) for s in range(300)) / 300.0
+    assert abs(freq.mean() - 0.25) < 1e-9 and freq.min() > 0.12 and freq.max() < 0.40
