@@ -183,9 +183,30 @@ def cpu_baseline(ops, budget_s=12.0):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": op.nnz / med, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": "%s (%d edges, F=%d), %d reps of the OpenMP oracle, median %.1f ms; the reference's "
-                      "CPU DGL kernel itself is not installable here" % (op.name, op.nnz, F, len(times), med * 1e3)}
+    out = {"value": op.nnz / med, "unit": "edges/s", "cores": threads, "kind": "port",
+           "sample": "%s (%d edges, F=%d), %d reps of the OpenMP oracle, median %.1f ms; the reference's "
+                     "CPU DGL kernel itself is not installable here" % (op.name, op.nnz, F, len(times), med * 1e3)}
+    # Beside it, the one call of the path the reference makes that IS runnable here: th.spmm on a sparse
+    # COO tensor (layers.py:312), on the disease kNN-64 graph, on the same host cores.
+    try:
+        kn = next(o for o in ops if o.name == "fgcn_fwd disease-knn")
+        S_ = kn.shard.local._S
+        adj = torch.sparse_coo_tensor(torch.stack([S_.dst.long().cpu(), S_.src.long().cpu()]),
+                                      kn.shard.local._coo_vals.cpu(), (S_.n_dst, S_.n_src))
+        Xc = kn.X.cpu()
+        torch.set_num_threads(threads)
+        torch.spmm(adj, Xc)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            torch.spmm(adj, Xc)
+            ts.append(time.perf_counter() - t0)
+        out["th_spmm_coo"] = {"value": kn.nnz / sorted(ts)[1], "unit": "edges/s", "torch_threads": threads,
+                              "sample": "torch.spmm(sparse_coo, X) as layers.py:312 calls it, %s, %d nnz, median of 3 = %.0f ms"
+                                        % (kn.name, kn.nnz, sorted(ts)[1] * 1e3)}
+    except Exception as exc:  # noqa: BLE001  (context number only)
+        out["th_spmm_coo"] = {"error": repr(exc)}
+    return out
 
 
 def committed_traffic():
