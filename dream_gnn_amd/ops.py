@@ -389,7 +389,9 @@ class CSRGraph:
 
     @staticmethod
     def _is_regular(max_deg: int, nnz: int, n_rows: int) -> bool:
-        return max_deg <= max(256, 8 * (nnz // max(n_rows, 1)))
+        # the sliced kernel streams a (row, slice) segment sequentially in one lane group: rows up
+        # to ~32x the average are a tail effect, rows of 10^5..10^6 edges (power laws) are not
+        return max_deg <= max(1024, 32 * (nnz // max(n_rows, 1)))
 
     def _validate(self):
         """One host sync: id range check and the maximum in-degree."""
