@@ -293,7 +293,46 @@ class _Structure:
     """Everything about a CSRGraph that depends on the edge list only (shared by value views)."""
 
     __slots__ = ("n_dst", "n_src", "dst", "src", "indptr", "indices", "eid", "plan", "planned", "t",
-                 "sliced", "sliced_t", "regular", "regular_t")
+                 "sliced", "sliced_t", "regular", "regular_t", "validated", "split", "split_t")
+
+
+# Rows longer than this are cut into virtual rows before the XCD-local kernel sees them (power-law
+# graphs): a (virtual row, slice) segment is then at most SPLIT_ROW_EDGES / 8 edges long.
+SPLIT_ROW_EDGES = 2048
+
+
+class _SplitSliced:
+    """XCD-local product for a graph with extremely long rows: every row is cut into virtual rows
+    of at most ``SPLIT_ROW_EDGES`` edges (in CSR order), the sliced kernel runs on the virtual-row
+    graph (regular by construction), and a second, tiny product adds each row's virtual rows back
+    together in order (``Y = C · Yv`` with ``C[row, v] = 1``; ``dst_scale`` applied there)."""
+
+    def __init__(self, indptr, eid, cols_coo, n_rows, n_cols):
+        dev = indptr.device
+        nnz = int(eid.shape[0])
+        deg = (indptr[1:] - indptr[:-1]).long()
+        nv = torch.clamp((deg + SPLIT_ROW_EDGES - 1) // SPLIT_ROW_EDGES, min=1)
+        vptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+        vptr[1:] = torch.cumsum(nv, 0)
+        self.n_virtual = int(vptr[-1])  # one host sync, at construction only
+        rows_p = torch.repeat_interleave(torch.arange(n_rows, device=dev), deg, output_size=nnz)
+        rank = torch.arange(nnz, device=dev) - indptr.long()[rows_p]
+        vrow_p = (vptr[rows_p] + rank // SPLIT_ROW_EDGES).to(torch.int32)
+        vrow_coo = torch.empty(nnz, dtype=torch.int32, device=dev)
+        vrow_coo[eid.long()] = vrow_p  # CSR position -> the caller's edge order
+        self.sliced = SlicedCSR(vrow_coo, cols_coo, self.n_virtual, n_cols)
+        self.c_indptr = vptr.to(torch.int32)
+        self.c_indices = torch.arange(self.n_virtual, dtype=torch.int32, device=dev)
+        self.c_plan = build_plan(self.c_indptr, self.n_virtual)
+        self.n_rows = n_rows
+
+    def spmm(self, X, src_scale, dst_scale, out, vals):
+        yv = self.sliced.spmm(X, src_scale, None, None, vals=vals)
+        F = yv.shape[1]
+        if out is None:
+            out = torch.empty((self.n_rows, F), dtype=torch.float32, device=yv.device)
+        return _launch_spmm(yv.device, self.c_indptr, self.c_indices, None, yv, None, dst_scale, out, self.c_plan,
+                            self.n_rows, self.n_virtual, F, F)
 
 
 class CSRGraph:
@@ -324,7 +363,8 @@ class CSRGraph:
         S.indptr, S.indices, S.eid = csr_from_coo(S.dst, S.src, S.n_dst, S.n_src, check_range=False)
         S.planned = planned
         S.plan = build_plan(S.indptr, int(S.indices.shape[0])) if planned else None
-        S.t = S.sliced = S.sliced_t = None
+        S.t = S.sliced = S.sliced_t = S.split = S.split_t = None
+        S.validated = bool(check_range)
         # `regular`: no destination row is extremely long, so the XCD-local kernel (which walks a
         # (row, slice) segment sequentially) is safe to use.  Known after the one readback below;
         # False for unchecked builds unless the caller vouches for it (they must not sync).
@@ -415,6 +455,17 @@ class CSRGraph:
         return (bool(regular) and F % 4 == 0 and SLICED_MIN_TABLE_BYTES <= table <= SLICED_MAX_TABLE_BYTES
                 and self.nnz >= SLICED_MIN_AVG_DEGREE * n_rows and n_rows * SlicedCSR.N_SLICES < 2 ** 31 - 1)
 
+    def _use_split(self, F: int, n_rows: int, n_cols: int, regular) -> bool:
+        """Long-row graphs (power laws): same table / degree criteria, rows cut into virtual rows.
+        Only for graphs that were validated at build (the split needs one host readback)."""
+        if FORCE_KERNEL is not None or regular is not False or not self._S.validated:
+            return False
+        table = n_cols * F * 4
+        n_virtual_bound = n_rows + self.nnz // SPLIT_ROW_EDGES
+        return (F % 4 == 0 and SLICED_MIN_TABLE_BYTES <= table <= SLICED_MAX_TABLE_BYTES
+                and self.nnz >= SLICED_MIN_AVG_DEGREE * n_virtual_bound
+                and n_virtual_bound * SlicedCSR.N_SLICES < 2 ** 31 - 1)
+
     def _t_struct(self):
         S = self._S
         if S.t is None:
@@ -451,6 +502,11 @@ class CSRGraph:
             if S.sliced is None:
                 S.sliced = SlicedCSR(S.dst, S.src, S.n_dst, S.n_src)
             return S.sliced.spmm(X, src_scale, dst_scale, out, vals=self._vals_for("sliced", S.sliced.eid))
+        if X.dim() == 2 and self._use_split(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
+            if S.split is None:
+                S.split = _SplitSliced(S.indptr, S.eid, S.src, S.n_dst, S.n_src)
+            return S.split.spmm(X, _prep_scale(src_scale, S.n_src, "src_scale"), _prep_scale(dst_scale, S.n_dst, "dst_scale"),
+                                out, self._vals_for("split", S.split.sliced.eid))
         return self._run(S.indptr, S.indices, self.vals, S.plan, S.n_dst, S.n_src, X, src_scale, dst_scale, out)
 
     def spmm_t(self, dY, src_scale=None, dst_scale=None, out=None):
@@ -459,11 +515,16 @@ class CSRGraph:
         indptr_t, indices_t, eid_t, plan_t = self._t_struct()
         if S.regular_t is None:  # one-time readback of the reversed graph's maximum degree
             max_deg = int((indptr_t[1:] - indptr_t[:-1]).max()) if self.nnz else 0
-            S.regular_t = bool(S.regular) and self._is_regular(max_deg, self.nnz, S.n_src)
+            S.regular_t = self._is_regular(max_deg, self.nnz, S.n_src)
         if dY.dim() == 2 and self._use_sliced(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):
             if S.sliced_t is None:
                 S.sliced_t = SlicedCSR(S.src, S.dst, S.n_src, S.n_dst)
             return S.sliced_t.spmm(dY, dst_scale, src_scale, out, vals=self._vals_for("sliced_t", S.sliced_t.eid))
+        if dY.dim() == 2 and self._use_split(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):
+            if S.split_t is None:
+                S.split_t = _SplitSliced(indptr_t, eid_t, S.dst, S.n_src, S.n_dst)
+            return S.split_t.spmm(dY, _prep_scale(dst_scale, S.n_dst, "dst_scale"), _prep_scale(src_scale, S.n_src, "src_scale"),
+                                  out, self._vals_for("split_t", S.split_t.sliced.eid))
         return self._run(indptr_t, indices_t, self._vals_for("csr_t", eid_t), plan_t, S.n_src, S.n_dst, dY,
                          dst_scale, src_scale, out)
 

@@ -134,6 +134,11 @@ def test_power_law_degrees_full_size(oracle, dev):
     X = torch.randn(ND, F, generator=gen, device=dev)
     y = g.spmm(X)
     assert torch.equal(y, g.spmm(X))
+    # not regular -> rows cut into virtual rows of <= 2048 edges, XCD-local kernel on those, ordered re-sum
+    assert not g.regular and g._S.split is not None and g._S.sliced is None
+    assert g._S.split.n_virtual == int(torch.clamp((deg + 2047) // 2048, min=1).sum())
+    y_planned = ops.spmm_csr_raw(g.indptr, g.indices, None, X, plan=g.plan)
+    assert float((y - y_planned).abs().max()) <= 1e-5 * float(y_planned.abs().max())
     ones = g.spmm(torch.ones(ND, F, device=dev))
     assert torch.equal(ones, deg.float()[:, None].expand(-1, F))  # exact while deg < 2^24
     order = torch.argsort(deg, descending=True)
@@ -143,6 +148,16 @@ def test_power_law_degrees_full_size(oracle, dev):
     lhs = (y.double() * W.double()).sum()
     rhs = (X.double() * g.spmm_t(W).double()).sum()
     assert abs(float(lhs - rhs)) <= 1e-6 * float((y.double().abs() * W.double().abs()).sum())
+    assert g.regular_t and g._S.sliced_t is not None  # source degrees are uniform: plain sliced backward
+    # the mirrored case: a graph whose SOURCE degrees are the power law (its transpose takes the split path)
+    gt = ops.CSRGraph(src, dst, ND, NS)
+    Xs = torch.randn(NS, F, generator=gen, device=dev)
+    V = torch.randn(ND, F, generator=gen, device=dev)
+    lhs = (gt.spmm(Xs).double() * V.double()).sum()
+    dxs = gt.spmm_t(V)
+    assert gt._S.split_t is not None
+    rhs = (Xs.double() * dxs.double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-6 * float((gt.spmm(Xs).double().abs() * V.double().abs()).sum())
 
 
 def test_edge_dropout_rebuild_full_size(cfg4, dev):
