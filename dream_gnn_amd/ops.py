@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -283,7 +284,7 @@ class SlicedCSR:
 # Measured on MI355X (tools/explore.py slicedcap, 10 M edges, F=128): sliced/planned time ratio
 # 1.0 at a 6 MB table, 1.9-2.4x at 13-51 MB, 1.2x at 102 MB, 1.0 at 205 MB; 1.55x at average
 # degree 100, 0.72x at 25 (a (row, slice) segment of 3 edges is all overhead).
-FORCE_KERNEL = {"planned": "planned", "sliced": "sliced"}.get(__import__("os").environ.get("DGMI_FORCE_KERNEL", ""))
+FORCE_KERNEL = {"planned": "planned", "sliced": "sliced"}.get(os.environ.get("DGMI_FORCE_KERNEL", ""))
 SLICED_MIN_TABLE_BYTES = 10 << 20
 SLICED_MAX_TABLE_BYTES = 160 << 20
 SLICED_MIN_AVG_DEGREE = 64
