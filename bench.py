@@ -294,8 +294,10 @@ def main():
     for op in ops:
         ms = [a.elapsed_time(b) for a, b in op.events]
         avg = sum(ms) / len(ms)
-        per_op[op.name] = {"avg_ms": round(avg, 4), "gedges_per_s": round(op.nnz / avg / 1e6, 2),
-                           "alg_GBps": round(op.bytes / avg / 1e6, 1)}
+        srt = sorted(ms)
+        per_op[op.name] = {"avg_ms": round(avg, 4), "median_ms": round(srt[len(srt) // 2], 4),
+                           "p10_ms": round(srt[len(srt) // 10], 4), "p90_ms": round(srt[(len(srt) * 9) // 10], 4),
+                           "gedges_per_s": round(op.nnz / avg / 1e6, 2), "alg_GBps": round(op.bytes / avg / 1e6, 1)}
         if op.dominant:
             dom_t += sum(ms) * 1e-3
             dom_b += op.bytes * len(ms)
