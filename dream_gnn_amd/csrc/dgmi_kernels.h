@@ -34,6 +34,24 @@ inline size_t plan_bytes(int64_t n_rows, int64_t nnz, int64_t chunk) {
          (size_t)(kPlanHeaderWords + 4 * (plan_items_cap(n_rows, nnz, chunk) + plan_long_cap(nnz, chunk)));
 }
 
+// Lanes-per-row for a 16-B-aligned width: the widest tile whose last tile is
+// still >= 85 % used (F=344 -> 32 lanes x 3 tiles, not 64 x 2 at 67 %).
+inline int pick_lpr(int64_t F) {
+  const int64_t f4 = (F + 3) / 4;
+  int best = 8;
+  double best_util = 0.0;
+  for (int lpr : {64, 32, 16, 8}) {
+    const int64_t tiles = (f4 + lpr - 1) / lpr;
+    const double util = (double)f4 / (double)(tiles * lpr);
+    if (util >= 0.85) return lpr;
+    if (util > best_util + 1e-9) {
+      best_util = util;
+      best = lpr;
+    }
+  }
+  return best;
+}
+
 struct SpmmArgs {
   const int32_t* indptr;
   const int32_t* indices;

@@ -249,10 +249,12 @@ hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s) {
   for (int64_t r0 = 0; r0 < a.n_dst; r0 += chunk) {
     const int64_t r1 = r0 + chunk < a.n_dst ? r0 + chunk : a.n_dst;
     hipError_t err;
-    if (a.F <= 32) err = launch_sliced<8>(a, r0, r1, s);
-    else if (a.F <= 64) err = launch_sliced<16>(a, r0, r1, s);
-    else if (a.F <= 128) err = launch_sliced<32>(a, r0, r1, s);
-    else err = launch_sliced<64>(a, r0, r1, s);
+    switch (pick_lpr(a.F)) {  // widest lane group whose last column tile is still >= 85 % used
+      case 8: err = launch_sliced<8>(a, r0, r1, s); break;
+      case 16: err = launch_sliced<16>(a, r0, r1, s); break;
+      case 32: err = launch_sliced<32>(a, r0, r1, s); break;
+      default: err = launch_sliced<64>(a, r0, r1, s); break;
+    }
     if (err != hipSuccess) return err;
     int64_t blocks = ((r1 - r0) * F4 + 255) / 256;
     if (blocks > 8192) blocks = 8192;

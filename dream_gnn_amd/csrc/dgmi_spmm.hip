@@ -216,24 +216,6 @@ hipError_t launch_dword(const SpmmArgs& a, int64_t segments, hipStream_t s) {
   return hipGetLastError();
 }
 
-// Lanes-per-row for a 16-B-aligned width: the widest tile whose last tile is
-// still >= 85 % used (F=344 -> 32 lanes x 3 tiles, not 64 x 2 at 67 %).
-inline int pick_lpr(int64_t F) {
-  const int64_t f4 = (F + 3) / 4;
-  int best = 8;
-  double best_util = 0.0;
-  for (int lpr : {64, 32, 16, 8}) {
-    const int64_t tiles = (f4 + lpr - 1) / lpr;
-    const double util = (double)f4 / (double)(tiles * lpr);
-    if (util >= 0.85) return lpr;
-    if (util > best_util + 1e-9) {
-      best_util = util;
-      best = lpr;
-    }
-  }
-  return best;
-}
-
 template <bool PLANNED>
 hipError_t dispatch(const SpmmArgs& a, int64_t segments, hipStream_t s) {
   const bool aligned = (a.F % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) &&
