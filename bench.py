@@ -256,6 +256,13 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if not os.path.exists(os.path.join(ROOT, "dream_gnn_amd", "libdgmi.so")):  # snapshot without build products
+        if local_rank == 0:
+            import __graft_entry__
+
+            __graft_entry__.build()
+        if world > 1:
+            dist.barrier()
     import dream_gnn_amd  # noqa: F401  (fails loudly if libdgmi.so is missing)
 
     comm_stream = torch.cuda.Stream() if world > 1 else None
