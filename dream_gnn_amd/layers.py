@@ -416,6 +416,18 @@ class GCN(nn.Module):
         x = F.dropout(F.relu(self.gc1(x, adj)), self.dropout, training=self.training)
         return self.gc2(x, adj)
 
+    def from_support(self, support, adj):
+        """The rest of :meth:`forward` given ``support = x @ gc1.weight``: FGCN applies one GCN to two
+        graphs with the same input (layers.py:263-270), so that dense product is computed once and
+        shared.  Same values and the same dropout draw as ``self(x, adj)``."""
+        if not isinstance(adj, ops.CSRGraph) and adj.device != support.device:
+            adj = adj.to(support.device)
+        h = ops.spmm_csr(adjacency_csr(adj), support)
+        if self.gc1.bias is not None:
+            h = h + self.gc1.bias
+        h = F.dropout(F.relu(h), self.dropout, training=self.training)
+        return self.gc2(h, adj)
+
 
 class FGCN(nn.Module):
     """layers.py:251-285: one GCN per node type, applied with shared weights to the similarity
@@ -431,17 +443,23 @@ class FGCN(nn.Module):
 
     def forward(self, drug_graph, drug_sim_feat, dis_graph, disease_sim_feat,
                 drug_feature_graph=None, disease_feature_graph=None):
-        emb1_sim = self.FGCN_drug(drug_sim_feat, drug_graph)
-        emb2_sim = self.FGCN_disease(disease_sim_feat, dis_graph)
         emb1_feat = emb2_feat = None
         if drug_feature_graph is not None and disease_feature_graph is not None:
-            emb1_feat = self.FGCN_drug(drug_sim_feat, drug_feature_graph)
-            emb2_feat = self.FGCN_disease(disease_sim_feat, disease_feature_graph)
+            # four GCN applications in the reference's order (so the dropout stream is unchanged);
+            # each GCN's first dense product x @ W1 is shared between its two graphs
+            sup_drug = torch.mm(drug_sim_feat, self.FGCN_drug.gc1.weight)
+            sup_dis = torch.mm(disease_sim_feat, self.FGCN_disease.gc1.weight)
+            emb1_sim = self.FGCN_drug.from_support(sup_drug, drug_graph)
+            emb2_sim = self.FGCN_disease.from_support(sup_dis, dis_graph)
+            emb1_feat = self.FGCN_drug.from_support(sup_drug, drug_feature_graph)
+            emb2_feat = self.FGCN_disease.from_support(sup_dis, disease_feature_graph)
             emb1 = torch.relu(self.drug_fusion(torch.cat([emb1_sim, emb1_feat], dim=1)))
             emb2 = torch.relu(self.disease_fusion(torch.cat([emb2_sim, emb2_feat], dim=1)))
             emb1 = F.dropout(emb1, p=self.dropout, training=self.training)
             emb2 = F.dropout(emb2, p=self.dropout, training=self.training)
         else:
+            emb1_sim = self.FGCN_drug(drug_sim_feat, drug_graph)
+            emb2_sim = self.FGCN_disease(disease_sim_feat, dis_graph)
             emb1, emb2 = emb1_sim, emb2_sim
         return emb1, emb2, emb1_sim, emb1_feat, emb2_sim, emb2_feat
 
