@@ -56,7 +56,7 @@ with open(os.path.join(out, tag + "_pmc_summary.csv"), "w", newline="") as fh:
     wr.writerows(rows)
 
 main = [r for r in rows if r["kernel"].startswith("spmm_sliced_vec4_kernel<32, false, true>")]
-red = [r for r in rows if r["kernel"].startswith("reduce_planes_kernel<true>")]
+red = [r for r in rows if r["kernel"].startswith("reduce_planes_kernel<true")]
 dom = None
 if main and red:
     dom = [{"kernel": main[0]["kernel"] + " + " + red[0]["kernel"],
