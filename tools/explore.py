@@ -195,3 +195,18 @@ if "widths2" in which:
         ms = timeit(lambda: g.spmm(X, out=Y))
         ms_p = timeit(lambda: ops.spmm_csr_raw(g.indptr, g.indices, None, X, out=Y, plan=g.plan))
         print(f"F={F}: auto {ms*1e3:.0f} us ({'sliced' if g._use_sliced(F, n_dst, n_src, g.regular) else 'planned'}) planned {ms_p*1e3:.0f} us  {E*(4*F+4)/ms/1e6:.0f} GB/s alg", flush=True)
+if "buildtimes" in which:
+    n_dst, n_src, E = 50_000, 100_000, 10_000_000
+    dst = torch.randint(0, n_dst, (E,), generator=gen, device=dev, dtype=torch.int32)
+    src = torch.randint(0, n_src, (E,), generator=gen, device=dev, dtype=torch.int32)
+    print("csr_from_coo (plain) %.3f ms" % timeit(lambda: ops.csr_from_coo(dst, src, n_dst), n=10))
+    print("SlicedCSR build      %.3f ms" % timeit(lambda: ops.SlicedCSR(dst, src, n_dst, n_src), n=10))
+    ip, _, _ = ops.csr_from_coo(dst, src, n_dst)
+    print("plan build           %.3f ms" % timeit(lambda: ops.build_plan(ip, E), n=10))
+    print("CSRGraph (validated: plain + plan + readback) %.3f ms" % timeit(lambda: ops.CSRGraph(dst, src, n_dst, n_src), n=10))
+    print("random_subset_mask   %.3f ms" % timeit(lambda: ops.random_subset_mask(E, 9_000_000, 7, dev), n=10))
+    print("torch.randperm(E)    %.3f ms" % timeit(lambda: torch.randperm(E, device=dev), n=10))
+    g = ops.CSRGraph(dst, src, n_dst, n_src)
+    X = torch.randn(n_src, 128, device=dev); g.spmm(X)
+    m = ops.random_subset_mask(E, 9_000_000, 7, dev)
+    print("masked view + its sliced values %.3f ms" % timeit(lambda: g.masked(m).spmm(X), n=10), "(product alone %.3f ms)" % timeit(lambda: g.spmm(X), n=10))
