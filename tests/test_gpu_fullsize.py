@@ -117,6 +117,7 @@ def test_weighted_knn64_full_size(oracle, dev):
     _rows_vs_oracle(oracle, g, X, [0, n - 1, int(deg.argmax()), int(deg.argmin())] + list(range(5000, 5020)), y)
 
 
+@pytest.mark.skipif(bool(__import__("os").environ.get("DGMI_FORCE_KERNEL")), reason="kernel choice is forced")
 def test_power_law_degrees_full_size(oracle, dev):
     """10 M edges with Zipf(1.2) destination degrees: the longest row holds ~2 M edges.  The
     planned launch must agree with the oracle there too (chunk partials summed in order)."""
