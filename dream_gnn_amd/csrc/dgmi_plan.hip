@@ -36,12 +36,15 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // counts[r] = (#chunks of row r) | (#chunks if the row is long, else 0) << 32
 __global__ __launch_bounds__(kBlock) void count_chunks_kernel(const int32_t* __restrict__ indptr,
-                                                              int64_t n_rows, int32_t chunk,
+                                                              int64_t n_rows, int64_t nnz, int32_t chunk,
                                                               uint64_t* __restrict__ counts,
                                                               uint32_t* __restrict__ is_long) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n_rows; r += stride) {
-    const int32_t deg = indptr[r + 1] - indptr[r];
+    // a well-formed indptr has 0 <= deg <= nnz; anything else (an indptr built from unchecked,
+    // out-of-range ids) is clamped so that the plan never outgrows the caps the host sized it by
+    int64_t deg = (int64_t)indptr[r + 1] - (int64_t)indptr[r];
+    deg = deg < 0 ? 0 : (deg > nnz ? nnz : deg);
     const uint32_t c = deg <= chunk ? 1u : (uint32_t)((deg + chunk - 1) / chunk);
     const bool lng = c > 1u;
     counts[r] = (uint64_t)c | ((uint64_t)(lng ? c : 0u) << 32);
@@ -52,7 +55,8 @@ __global__ __launch_bounds__(kBlock) void count_chunks_kernel(const int32_t* __r
 __global__ __launch_bounds__(kBlock) void fill_plan_kernel(
     const int32_t* __restrict__ indptr, int64_t n_rows, int32_t chunk,
     const uint64_t* __restrict__ counts, const uint64_t* __restrict__ offs,
-    const uint32_t* __restrict__ long_offs, int64_t items_cap, int32_t* __restrict__ plan) {
+    const uint32_t* __restrict__ long_offs, int64_t items_cap, int64_t long_cap,
+    int64_t slots_cap, int32_t* __restrict__ plan) {
   int4* items = reinterpret_cast<int4*>(plan + kPlanHeaderWords);
   int4* longs = items + items_cap;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -61,19 +65,21 @@ __global__ __launch_bounds__(kBlock) void fill_plan_kernel(
     const uint32_t c = (uint32_t)(counts[r] & 0xffffffffu);
     const uint32_t item0 = (uint32_t)(offs[r] & 0xffffffffu);
     const uint32_t slot0 = (uint32_t)(offs[r] >> 32);
+    // Every store is bounded by the caps (they hold for any well-formed indptr; a malformed one
+    // — see count_chunks_kernel — loses items instead of writing past the plan buffer).
     if (c == 1u) {
-      items[item0] = make_int4((int)r, start, end, -1);
+      if ((int64_t)item0 < items_cap) items[item0] = make_int4((int)r, start, max(start, end), -1);
     } else {
-      for (uint32_t k = 0; k < c; ++k) {
+      for (uint32_t k = 0; k < c && (int64_t)item0 + k < items_cap && (int64_t)slot0 + k < slots_cap; ++k) {
         const int32_t s = start + (int32_t)k * chunk;
         const int32_t e = min(s + chunk, end);
         items[item0 + k] = make_int4((int)r, s, e, (int)(slot0 + k));
       }
-      longs[long_offs[r]] = make_int4((int)r, (int)slot0, (int)c, 0);
+      if ((int64_t)long_offs[r] < long_cap) longs[long_offs[r]] = make_int4((int)r, (int)slot0, (int)c, 0);
     }
     if (r == n_rows - 1) {
-      plan[kPlanNumItems] = (int32_t)(item0 + c);
-      plan[kPlanNumLong] = (int32_t)(long_offs[r] + (c > 1u ? 1u : 0u));
+      plan[kPlanNumItems] = (int32_t)min((int64_t)item0 + c, items_cap);
+      plan[kPlanNumLong] = (int32_t)min((int64_t)long_offs[r] + (c > 1u ? 1 : 0), long_cap);
       plan[kPlanNumSlots] = (int32_t)(slot0 + (c > 1u ? c : 0u));
       plan[kPlanChunk] = chunk;
     }
@@ -118,7 +124,7 @@ hipError_t spmm_plan_build(const int32_t* indptr, int64_t n_rows, int64_t nnz, i
   void* tmp = ws + off_tmp;
 
   hipLaunchKernelGGL(count_chunks_kernel, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, indptr,
-                     n_rows, (int32_t)chunk, counts, is_long);
+                     n_rows, nnz, (int32_t)chunk, counts, is_long);
   err = rocprim::exclusive_scan(tmp, scan64, counts, offs, (uint64_t)0, (size_t)n_rows,
                                 rocprim::plus<uint64_t>(), s);
   if (err != hipSuccess) return err;
@@ -127,7 +133,7 @@ hipError_t spmm_plan_build(const int32_t* indptr, int64_t n_rows, int64_t nnz, i
   if (err != hipSuccess) return err;
   hipLaunchKernelGGL(fill_plan_kernel, dim3(grid_for(n_rows)), dim3(kBlock), 0, s, indptr, n_rows,
                      (int32_t)chunk, counts, offs, long_offs, plan_items_cap(n_rows, nnz, chunk),
-                     plan);
+                     plan_long_cap(nnz, chunk), plan_slots_cap(nnz, chunk), plan);
   return hipGetLastError();
 }
 

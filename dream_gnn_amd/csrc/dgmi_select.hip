@@ -91,9 +91,21 @@ __global__ __launch_bounds__(kBlock) void mask_kernel(int64_t E, uint64_t seed, 
 }
 
 // one thread: among the edges whose hash equals the threshold keep the `remaining` smallest ids
-__global__ void ties_kernel(SelectState* st, float* __restrict__ mask) {
+__global__ void ties_kernel(int64_t E, uint64_t seed, SelectState* st, float* __restrict__ mask) {
   if (threadIdx.x != 0) return;
-  const uint32_t n = st->n_ties < (uint32_t)kTieCap ? st->n_ties : (uint32_t)kTieCap;
+  if (st->n_ties > (uint32_t)kTieCap) {
+    // More ties than the list holds (expected count is E / 2^32 < 1, so this is a degenerate
+    // hash / seed): stay exact with a sequential scan in edge-id order instead of mis-counting.
+    const uint32_t thr = st->prefix;
+    int64_t left = st->remaining;
+    for (int64_t e = 0; e < E && left > 0; ++e)
+      if (edge_hash(seed, (uint64_t)e) == thr) {
+        mask[e] = 1.f;
+        --left;
+      }
+    return;
+  }
+  const uint32_t n = st->n_ties;
   for (uint32_t i = 1; i < n; ++i) {  // insertion sort by edge id
     const uint32_t v = st->ties[i];
     uint32_t j = i;
@@ -125,7 +137,7 @@ hipError_t random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float*
     hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(64), 0, s, st, shift);
   }
   hipLaunchKernelGGL(mask_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, E, seed, st, mask);
-  hipLaunchKernelGGL(ties_kernel, dim3(1), dim3(64), 0, s, st, mask);
+  hipLaunchKernelGGL(ties_kernel, dim3(1), dim3(64), 0, s, E, seed, st, mask);
   return hipGetLastError();
 }
 

@@ -169,16 +169,21 @@ class HeteroGraph:
     Constructor arguments follow ``dgl.heterograph(data_dict, num_nodes_dict=...)`` as the
     reference calls it (data_loader.py:448, augmentation.py:65).  Edge order inside an edge
     type is the caller's order; the CSR build is stable, so that order is the in-row
-    summation order, as with DGL.
+    summation order, as with DGL.  Node types and relation triples are kept SORTED, as
+    ``dgl.heterograph`` does (dgl/convert.py sorts both "to have a deterministic order" — from
+    memory of DGL's public source; DGL is absent here, so this is unpinned): it is the order
+    ``HeteroGraphConv`` runs the per-relation modules — i.e. the order of their dropout draws —
+    and the order ``random_edge_dropout`` walks the edge types (augmentation.py:24).
     """
 
     def __init__(self, data_dict: Dict[CanonicalEType, Tuple[torch.Tensor, torch.Tensor]],
                  num_nodes_dict: Dict[str, int], device=None):
-        self._num_nodes = {k: int(v) for k, v in num_nodes_dict.items()}
+        self._num_nodes = {k: int(num_nodes_dict[k]) for k in sorted(num_nodes_dict)}
         self._ndata: Dict[str, dict] = {nt: {} for nt in self._num_nodes}
         self._rels: Dict[CanonicalEType, RelationGraph] = {}
         self.nodes = _NodeSpace(self._ndata)
-        for can, (src, dst) in data_dict.items():
+        for can in sorted(data_dict):
+            src, dst = data_dict[can]
             st, _, dt = can
             src = torch.as_tensor(src)
             dst = torch.as_tensor(dst)

@@ -293,9 +293,9 @@ class GCMCLayer(nn.Module):
             if fr is None:
                 return None
             plans[nt] = fr
-        # dropout masks are drawn in canonical relation order, one (N_src, 1) draw per slice,
-        # exactly as the per-slice path does (layers.py:224)
-        drops, weights = {}, {}
+        # Pass 1 — every fit check, before any RNG is consumed: a late `return None` after some
+        # dropout draws would make the per-slice fallback redraw them and shift the stream.
+        weights = {}
         for can in graph.canonical_etypes:
             stype, etype, _ = can
             conv = self.conv.mods[etype]
@@ -306,17 +306,30 @@ class GCMCLayer(nn.Module):
                 raise DGMIError("External weight provided but module also has its own weight parameter, "
                                 "please set weight=False.")
             w = ext_w if ext_w is not None else conv.weight
-            if (x is None or w is None or conv.device is not None or x.dim() != 2 or x.shape[1] == 3
+            if (x is None or w is None or x.dim() != 2 or x.shape[1] == 3
                     or x.shape[0] != rel.number_of_src_nodes() or rel.srcdata["cj"].shape[0] != x.shape[0]):
                 return None
-            drops[can] = conv.dropout(rel.srcdata["cj"]).view(-1)
+            # The reference's Net always passes device=args.device (model.py:19,40) and the slice
+            # module then moves feat/cj/ci there (layers.py:107-110 style `.to(device)`); the fused
+            # form applies whenever that move would be a no-op.
+            if conv.device is not None:
+                want = torch.device(conv.device)
+                if want.type == "cuda" and want.index is None:
+                    want = torch.device("cuda", torch.cuda.current_device())
+                if any(t.device != want for t in (x, rel.srcdata["cj"], rel.dstdata["ci"])):
+                    return None
             weights[can] = w
+        for nt, (csr, cans) in plans.items():
+            if any(weights[c].shape != weights[cans[0]].shape for c in cans):
+                return None
+        # Pass 2 — dropout masks in canonical relation order, one (N_src, 1) draw per slice, exactly
+        # as the per-slice path does (layers.py:224)
+        drops = {can: self.conv.mods[can[1]].dropout(graph[can].srcdata["cj"]).view(-1)
+                 for can in graph.canonical_etypes}
         out = {}
         for nt, (csr, cans) in plans.items():
             x = inputs[cans[0][0]]
             width = weights[cans[0]].shape[1]
-            if any(weights[c].shape != weights[cans[0]].shape for c in cans):
-                return None
             pad = -width % 4  # keep rows 16-B aligned (341 -> 344), see GCMCGraphConv.forward
             w_cat = torch.cat([F.pad(weights[c], (0, pad)) if pad else weights[c] for c in cans], dim=1)
             feat = torch.matmul(x, w_cat).view(x.shape[0] * len(cans), width + pad)  # rows [u][r]

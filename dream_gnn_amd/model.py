@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .layers import FGCN, GCMCLayer, get_activation
 
 
@@ -30,12 +31,8 @@ class Attention(nn.Module):
         return (beta * z).sum(1), beta
 
 
-from . import ops
-
-
 class MLPDecoder(nn.Module):
     """Per-edge gather-concat then 2F->128->64->1 MLP — layers.py:341-375."""
-
 
     def __init__(self, in_units, dropout_rate=0.1):
         super().__init__()

@@ -64,13 +64,16 @@ def _check(t, dtype, name, ndim=None):
 
 
 def csr_from_coo(row: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: int = 0,
-                 check_range: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                 check_range: bool = False, return_flag: bool = False):
     """Stable COO -> CSR on the device: ``(indptr[n_rows+1], indices[E], eid[E])``, all int32.
 
     ``eid`` is the stable permutation (``argsort(row, kind='stable')``); duplicates are kept.
     Replaces DGL's COO->CSR behind ``dgl.heterograph`` (data_loader.py:448, augmentation.py:65).
     ``check_range=True`` reads the kernel's error flag back (one host sync) and raises if a row
     id is outside ``[0, n_rows)`` or, with ``n_cols > 0``, a column id outside ``[0, n_cols)``.
+    ``return_flag=True`` appends that flag as a 1-element int32 device tensor instead (no sync), for
+    callers that fold it into a readback of their own.  With the flag set the arrays are in bounds
+    but meaningless: nothing may be derived from them.
     """
     dev = _require_device(row, col)
     _check(row, torch.int32, "row", 1)
@@ -93,6 +96,8 @@ def csr_from_coo(row: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: int 
         if check_range and int(ws[:4].view(torch.int32).item()) != 0:
             raise RuntimeError("csr_from_coo: an id is outside [0, %d) x [0, %s)"
                                % (n_rows, n_cols if n_cols > 0 else "unchecked"))
+    if return_flag:
+        return indptr, indices, eid, ws[:4].view(torch.int32).clone()
     return indptr, indices, eid
 
 
@@ -361,9 +366,8 @@ class CSRGraph:
         S.src = src.to(torch.int32).contiguous()
         if vals is not None and vals.shape[0] != S.dst.shape[0]:
             raise RuntimeError("vals/edge-list length mismatch")
-        S.indptr, S.indices, S.eid = csr_from_coo(S.dst, S.src, S.n_dst, S.n_src, check_range=False)
+        S.indptr, S.indices, S.eid, flag = csr_from_coo(S.dst, S.src, S.n_dst, S.n_src, return_flag=True)
         S.planned = planned
-        S.plan = build_plan(S.indptr, int(S.indices.shape[0])) if planned else None
         S.t = S.sliced = S.sliced_t = S.split = S.split_t = None
         S.validated = bool(check_range)
         # `regular`: no destination row is extremely long, so the XCD-local kernel (which walks a
@@ -373,7 +377,11 @@ class CSRGraph:
         S.regular_t = regular_t if (regular_t is not None or check_range) else False
         self._set_values(None if vals is None else vals.to(torch.float32).contiguous())
         if check_range:
-            self._validate()
+            # ids are checked BEFORE anything is derived from the CSR: the sort of an edge list with
+            # ids outside [0, n) leaves indptr in bounds but meaningless, and a launch plan built
+            # from it would be garbage (the plan kernels clamp, the product would still be wrong)
+            self._validate(flag)
+        S.plan = build_plan(S.indptr, int(S.indices.shape[0])) if planned else None
 
     # -- values -----------------------------------------------------------------------------------
     def _set_values(self, coo_vals):
@@ -434,20 +442,19 @@ class CSRGraph:
         # to ~32x the average are a tail effect, rows of 10^5..10^6 edges (power laws) are not
         return max_deg <= max(1024, 32 * (nnz // max(n_rows, 1)))
 
-    def _validate(self):
-        """One host sync: id range check and the maximum in-degree."""
+    def _validate(self, flag: torch.Tensor):
+        """One host sync: the range flag of the device COO->CSR and the maximum in-degree."""
         S = self._S
         if self.nnz == 0:
             S.regular = True
             return
-        stats = torch.stack([S.dst.min(), S.dst.max(), S.src.min(), S.src.max(),
-                             (S.indptr[1:] - S.indptr[:-1]).max()]).tolist()
-        dlo, dhi, slo, shi, max_deg = (int(v) for v in stats)
-        if dlo < 0 or dhi >= S.n_dst:
-            raise RuntimeError("destination id out of range [0, %d): min %d max %d" % (S.n_dst, dlo, dhi))
-        if slo < 0 or shi >= S.n_src:
+        bad, max_deg = torch.stack([flag.reshape(()), (S.indptr[1:] - S.indptr[:-1]).max()]).tolist()
+        if bad:  # error path only: say which side and by how much
+            dlo, dhi, slo, shi = (int(v) for v in torch.stack([S.dst.min(), S.dst.max(), S.src.min(), S.src.max()]).tolist())
+            if dlo < 0 or dhi >= S.n_dst:
+                raise RuntimeError("destination id out of range [0, %d): min %d max %d" % (S.n_dst, dlo, dhi))
             raise RuntimeError("source id out of range [0, %d): min %d max %d" % (S.n_src, slo, shi))
-        S.regular = self._is_regular(max_deg, self.nnz, S.n_dst)
+        S.regular = self._is_regular(int(max_deg), self.nnz, S.n_dst)
 
     def _use_sliced(self, F: int, n_rows: int, n_cols: int, regular: bool) -> bool:
         if FORCE_KERNEL is not None:  # debugging / A-B aid: DGMI_FORCE_KERNEL=planned|sliced
@@ -563,8 +570,20 @@ def spmm_csr(g: CSRGraph, X: torch.Tensor, src_scale: Optional[torch.Tensor] = N
 # ---------------------------------------------------------------------------------------------
 # (f2) decoder edge gather-concat: graph.apply_edges(udf_u_mul_e) — layers.py:364,378-379
 # ---------------------------------------------------------------------------------------------
-def gather_concat_raw(src, dst, A, B, out=None) -> torch.Tensor:
-    """``out[e] = cat(A[src[e]], B[dst[e]])`` through ``dgmi_gather_concat_f32`` (no autograd)."""
+def _check_tables(A, B, n_src, n_dst):
+    """The feature tables must cover the id ranges the edge list was validated against
+    (``EdgePairs``): DGL would raise on a node-data / node-count mismatch; reading past a short
+    table on the GPU must not be an option."""
+    if n_src is not None and A.shape[0] < n_src:
+        raise RuntimeError("source feature table has %d rows, the edge list addresses %d source nodes" % (A.shape[0], n_src))
+    if n_dst is not None and B.shape[0] < n_dst:
+        raise RuntimeError("destination feature table has %d rows, the edge list addresses %d destination nodes"
+                           % (B.shape[0], n_dst))
+
+
+def gather_concat_raw(src, dst, A, B, out=None, n_src=None, n_dst=None) -> torch.Tensor:
+    """``out[e] = cat(A[src[e]], B[dst[e]])`` through ``dgmi_gather_concat_f32`` (no autograd).
+    ``n_src`` / ``n_dst``: the node counts ``src`` / ``dst`` ids were range-checked against."""
     dev = _require_device(src, dst, A, B, out)
     _check(src, torch.int32, "src", 1)
     _check(dst, torch.int32, "dst", 1)
@@ -572,6 +591,7 @@ def gather_concat_raw(src, dst, A, B, out=None) -> torch.Tensor:
         raise RuntimeError("src/dst length mismatch")
     A, n_a, Fa, lda = _prep_dense(A)
     B, n_b, Fb, ldb = _prep_dense(B)
+    _check_tables(A, B, n_src, n_dst)
     E = src.shape[0]
     if out is None:
         out = torch.empty((E, Fa + Fb), dtype=torch.float32, device=dev)
@@ -624,7 +644,7 @@ class _GatherConcat(torch.autograd.Function):
     def forward(ctx, A, B, pairs: EdgePairs):
         ctx.pairs = pairs
         ctx.Fa, ctx.Fb = A.shape[1], B.shape[1]
-        return gather_concat_raw(pairs.src, pairs.dst, A, B)
+        return gather_concat_raw(pairs.src, pairs.dst, A, B, n_src=pairs.n_src, n_dst=pairs.n_dst)
 
     @staticmethod
     def backward(ctx, dOut):
@@ -643,13 +663,14 @@ def gather_concat(pairs: EdgePairs, A: torch.Tensor, B: torch.Tensor) -> torch.T
     return _GatherConcat.apply(A, B, pairs)
 
 
-def gather_add_raw(src, dst, A, B, bias=None, out=None) -> torch.Tensor:
+def gather_add_raw(src, dst, A, B, bias=None, out=None, n_src=None, n_dst=None) -> torch.Tensor:
     """``out[e] = A[src[e]] + B[dst[e]] (+ bias)`` through ``dgmi_gather_add_f32`` (no autograd)."""
     dev = _require_device(src, dst, A, B, bias, out)
     _check(src, torch.int32, "src", 1)
     _check(dst, torch.int32, "dst", 1)
     A, _, F, lda = _prep_dense(A)
     B, _, Fb, ldb = _prep_dense(B)
+    _check_tables(A, B, n_src, n_dst)
     if F != Fb:
         raise RuntimeError("A and B must have the same width, got %d and %d" % (F, Fb))
     if bias is not None:
@@ -669,7 +690,7 @@ class _GatherAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, A, B, bias, pairs: EdgePairs):
         ctx.pairs = pairs
-        return gather_add_raw(pairs.src, pairs.dst, A, B, bias)
+        return gather_add_raw(pairs.src, pairs.dst, A, B, bias, n_src=pairs.n_src, n_dst=pairs.n_dst)
 
     @staticmethod
     def backward(ctx, dOut):

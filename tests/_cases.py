@@ -81,6 +81,9 @@ def case_spmm(dev, F):
         tag = "weighted" if weighted else "copy_u"
         close(y, g["y_" + tag], 1e-5, "y_" + tag)
         close(x.grad, g["dx_" + tag], 1e-5, "dx_" + tag)
+        if not weighted:  # the same sum through ATen (torch.spmm on unit values): third-party pin
+            close(y, g["y_unit_spmm"], 1e-5, "y_unit_spmm")
+            close(x.grad, g["dx_unit_spmm"], 1e-5, "dx_unit_spmm")
         deg = np.bincount(g["dst"], minlength=n_dst)
         assert np.all(y.detach().cpu().numpy()[deg == 0] == 0)
 
@@ -123,21 +126,23 @@ def build_enc(g, dev):
                              symm=True, device=dev).int()
 
 
-def case_gcmc_layer(dev, name, fuse=True):
+def case_gcmc_layer(dev, name, fuse=True, device_arg=None, dropout_rate=0.0, seed=None):
     from dream_gnn_amd import layers as L
 
     g = load("gcmc_layer_" + name)
     uin, min_, msg, out, ini, share = [int(v) for v in g["cfg"]]
     act = str(g["act"])
-    layer = L.GCMCLayer([0, 1], uin, min_, msg, out, dropout_rate=0.0, agg="sum",
+    layer = L.GCMCLayer([0, 1], uin, min_, msg, out, dropout_rate=dropout_rate, agg="sum",
                         agg_act=L.get_activation(None if act == "None" else act), ini=bool(ini),
-                        share_user_item_param=bool(share))
+                        share_user_item_param=bool(share), device=device_arg)
     layer = load_sd(layer, g, dev)
     layer.train()
     layer.fuse_relations = fuse
     enc = build_enc(g, dev)
     drug = T(g["drug"], dev).requires_grad_(True)
     dis = T(g["dis"], dev).requires_grad_(True)
+    if seed is not None:
+        torch.manual_seed(seed)
     o_drug, o_dis = layer(enc, drug, dis)
     ((o_drug * T(g["d_drug"], dev)).sum() + (o_dis * T(g["d_dis"], dev)).sum()).backward()
     fused = enc.__dict__.get("_fused", {})

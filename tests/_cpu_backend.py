@@ -13,9 +13,17 @@ import torch
 from oracle import oracle as O
 
 
-def csr_from_coo(row, col, n_rows, n_cols=0, check_range=False):
-    indptr, indices, eid = O.csr_from_coo(row.cpu().numpy(), col.cpu().numpy(), int(n_rows))
-    return torch.from_numpy(indptr), torch.from_numpy(indices), torch.from_numpy(eid)
+def csr_from_coo(row, col, n_rows, n_cols=0, check_range=False, return_flag=False):
+    r, c = row.cpu().numpy(), col.cpu().numpy()
+    bad = bool(r.size) and (r.min() < 0 or r.max() >= n_rows or (n_cols > 0 and (c.min() < 0 or c.max() >= n_cols)))
+    if bad:  # what the device build leaves behind with the flag set: arrays in bounds, content meaningless
+        if check_range:
+            raise RuntimeError("csr_from_coo: an id is out of range")
+        out = (torch.zeros(n_rows + 1, dtype=torch.int32), torch.zeros(r.size, dtype=torch.int32),
+               torch.arange(r.size, dtype=torch.int32))
+    else:
+        out = tuple(torch.from_numpy(a) for a in O.csr_from_coo(r, c, int(n_rows)))
+    return out + (torch.tensor([int(bad)], dtype=torch.int32),) if return_flag else out
 
 
 def gather_f32(values, perm):
@@ -32,7 +40,7 @@ def spmm_csr_raw(indptr, indices, vals, X, src_scale=None, dst_scale=None, out=N
     return y
 
 
-def gather_concat_raw(src, dst, A, B, out=None):
+def gather_concat_raw(src, dst, A, B, out=None, n_src=None, n_dst=None):
     y = torch.from_numpy(O.gather_concat(src.numpy(), dst.numpy(), A.detach().numpy(), B.detach().numpy()))
     if out is not None:
         out.copy_(y)
@@ -40,7 +48,7 @@ def gather_concat_raw(src, dst, A, B, out=None):
     return y
 
 
-def gather_add_raw(src, dst, A, B, bias=None, out=None):
+def gather_add_raw(src, dst, A, B, bias=None, out=None, n_src=None, n_dst=None):
     y = A.detach()[src.long()] + B.detach()[dst.long()]
     if bias is not None:
         y = y + bias.detach()

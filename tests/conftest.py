@@ -10,14 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # The native pieces are git-ignored build products: make sure they exist before collection
-    # (hipcc cross-compiles gfx950 without a GPU; a no-op when they are up to date).
-    import subprocess
+    # The native pieces are git-ignored build products: bring them up to date before collection
+    # (hipcc cross-compiles gfx950 without a GPU; make is a no-op when they are fresh) — and before
+    # anything in this process touches the GPU.
+    import __graft_entry__
 
-    if not os.path.exists(os.path.join(ROOT, "dream_gnn_amd", "libdgmi.so")):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "dream_gnn_amd", "csrc"), "-j4"])
-    if not os.path.exists(os.path.join(ROOT, "oracle", "libdgmi_oracle.so")):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    __graft_entry__.ensure_built()
 
 
 @pytest.fixture(scope="session")

@@ -69,11 +69,17 @@ class DGLGraph:
     """Heterograph (possibly with one relation = a relation slice)."""
 
     def __init__(self, data_dict, num_nodes_dict, ndata=None, idtype=torch.int64):
-        self._nn = dict(num_nodes_dict)
+        # DGL's ``heterograph`` sorts node types and relation triples ("to have a deterministic
+        # order for the same set of type names", dgl/convert.py — from memory of DGL's public
+        # source, unverifiable here): canonical_etypes / ntypes iterate in sorted order, which is
+        # the order HeteroGraphConv runs the sub-modules (their dropout draws) and the order
+        # augmentation.py:24 walks the edge types.
+        self._nn = {nt: num_nodes_dict[nt] for nt in sorted(num_nodes_dict)}
         self._ndata = ndata if ndata is not None else {nt: {} for nt in self._nn}
         self._rel = {}
         self._edata = {}
-        for can, (s, d) in data_dict.items():
+        for can in sorted(data_dict):
+            s, d = data_dict[can]
             s = torch.as_tensor(s).to(idtype)
             d = torch.as_tensor(d).to(idtype)
             self._rel[can] = (s, d)

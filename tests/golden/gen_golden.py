@@ -9,7 +9,9 @@ they lie and stores only inputs / parameters / outputs as arrays.
 Provenance of each file (what produced the expected values):
   csr_*.npz        numpy ``argsort(kind='stable')``                       (independent of oracle/)
   spmm_*.npz       weighted: the installed ``torch.spmm`` + its autograd  (reference layers.py:312)
-                   unweighted: ``dgl_standin`` update_all (torch index_add) — NOT DGL, see below
+                   unweighted: ``y_copy_u`` = ``dgl_standin`` update_all (torch index_add) — NOT DGL,
+                   see below — and beside it ``y_unit_spmm`` = the installed ``torch.spmm`` on the same
+                   edges with unit values (independent third-party code for the same sum)
   simgraph_*.npz   reference ``DrugDataLoader._create_similarity_graph`` + ``utils.normalize`` +
                    ``utils.sparse_mx_to_torch_sparse_tensor``, ``augmentation.random_edge_dropout_sparse``
   encgraph_*.npz   reference ``DrugDataLoader._generate_enc_graph`` (ci/cj)  [graph ctor: stand-in]
@@ -104,8 +106,14 @@ def gen_spmm():
         g.update_all(dgl.function.copy_u("h", "m"), dgl.function.sum("m", "h"))
         y2 = g.dstdata["h"]
         y2.backward(th.from_numpy(dY))
+        # the same unweighted sum through ATen: torch.spmm with unit values on the same COO
+        x3 = th.from_numpy(X).requires_grad_(True)
+        unit = th.sparse_coo_tensor(th.from_numpy(np.vstack([dst, src])), th.ones(E), (n_dst, n_src))
+        y3 = th.spmm(unit, x3)
+        y3.backward(th.from_numpy(dY))
         save("spmm_F%d" % F, dst=dst.astype(np.int32), src=src.astype(np.int32), val=val, X=X, dY=dY,
-             n_dst=n_dst, n_src=n_src, y_weighted=y, dx_weighted=x.grad, y_copy_u=y2, dx_copy_u=x2.grad)
+             n_dst=n_dst, n_src=n_src, y_weighted=y, dx_weighted=x.grad, y_copy_u=y2, dx_copy_u=x2.grad,
+             y_unit_spmm=y3, dx_unit_spmm=x3.grad)
 
 
 def _fake_loader(symm=True, n_drug=0, n_dis=0):
@@ -210,10 +218,15 @@ def gen_gcmc_layer():
         "shared_noini": (12, 12, 16, 6, False, True, "leaky"),
         "unshared": (12, 10, 24, 6, True, False, "relu"),           # own weights per etype, ifc != ufc
         "shareflag_dimdiff": (12, 10, 24, 6, True, True, None),     # share flag but dims differ -> own weights
+        # dropout on: pins the ORDER of the RNG draws (one (N_src,1) draw per relation in canonical
+        # etype order, then the two layer-level draws) — CPU RNG stream, relative to the stand-in's
+        # (sorted, DGL-style) relation order
+        "shared_dropout": (12, 12, 16, 6, False, True, "leaky"),
     }
     for name, (uin, min_, msg, out, ini, share, act) in cfgs.items():
         th.manual_seed(11)
-        layer = ref_layers.GCMCLayer([0, 1], uin, min_, msg, out, dropout_rate=0.0, agg="sum",
+        p_drop = 0.3 if name == "shared_dropout" else 0.0
+        layer = ref_layers.GCMCLayer([0, 1], uin, min_, msg, out, dropout_rate=p_drop, agg="sum",
                                      agg_act=ref_utils.get_activation(act), ini=ini,
                                      share_user_item_param=share)
         layer.train()
@@ -221,6 +234,7 @@ def gen_gcmc_layer():
         dis = th.from_numpy(rng.standard_normal((n_dis, min_)).astype(np.float32)).requires_grad_(True)
         d_drug = th.from_numpy(rng.standard_normal((n_drug, out)).astype(np.float32))
         d_dis = th.from_numpy(rng.standard_normal((n_dis, out)).astype(np.float32))
+        th.manual_seed(31337)  # the forward's dropout draws start from here
         o_drug, o_dis = layer(g, drug, dis)
         ((o_drug * d_drug).sum() + (o_dis * d_dis).sum()).backward()
         arrays = dict(drug_ids=pairs[0], dis_ids=pairs[1], values=vals, n_drug=n_drug, n_dis=n_dis,

@@ -8,6 +8,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ND, NS, E, F = 100_000, 50_000, 10_000_000, 128
+# DGMI_FORCE_KERNEL=planned|sliced pins the kernel choice (A/B aid): the numeric checks below still
+# run, only the assertions about WHICH kernel was picked are skipped.
+FORCED = bool(__import__("os").environ.get("DGMI_FORCE_KERNEL"))
 
 
 @pytest.fixture(scope="module")
@@ -56,7 +59,6 @@ def test_csr_build_is_a_stable_sort_at_full_size(cfg4):
     assert torch.equal(eid2.long(), torch.arange(E, device=eid.device))
 
 
-@pytest.mark.skipif(bool(__import__("os").environ.get("DGMI_FORCE_KERNEL")), reason="kernel choice is forced")
 def test_spmm_full_size_properties(oracle, cfg4, dev):
     from dream_gnn_amd import ops, synth
 
@@ -76,7 +78,7 @@ def test_spmm_full_size_properties(oracle, cfg4, dev):
     # config 4's 51 MB feature table selects the XCD-local sliced kernel: same product, summed
     # slice by slice
     y = g.spmm(X, cj, ci)
-    assert g._sliced is not None and g.regular
+    assert g.regular and (FORCED or g._sliced is not None)
     assert float((y - y_rows).abs().max()) <= 1e-5 * float(y_rows.abs().max())
     assert torch.equal(y, g.spmm(X, cj, ci))  # run-to-run reproducible
     # linearity
@@ -117,7 +119,6 @@ def test_weighted_knn64_full_size(oracle, dev):
     _rows_vs_oracle(oracle, g, X, [0, n - 1, int(deg.argmax()), int(deg.argmin())] + list(range(5000, 5020)), y)
 
 
-@pytest.mark.skipif(bool(__import__("os").environ.get("DGMI_FORCE_KERNEL")), reason="kernel choice is forced")
 def test_power_law_degrees_full_size(oracle, dev):
     """10 M edges with Zipf(1.2) destination degrees: the longest row holds ~2 M edges.  The
     planned launch must agree with the oracle there too (chunk partials summed in order)."""
@@ -136,8 +137,10 @@ def test_power_law_degrees_full_size(oracle, dev):
     y = g.spmm(X)
     assert torch.equal(y, g.spmm(X))
     # not regular -> rows cut into virtual rows of <= 2048 edges, XCD-local kernel on those, ordered re-sum
-    assert not g.regular and g._S.split is not None and g._S.sliced is None
-    assert g._S.split.n_virtual == int(torch.clamp((deg + 2047) // 2048, min=1).sum())
+    assert not g.regular
+    if not FORCED:
+        assert g._S.split is not None and g._S.sliced is None
+        assert g._S.split.n_virtual == int(torch.clamp((deg + 2047) // 2048, min=1).sum())
     y_planned = ops.spmm_csr_raw(g.indptr, g.indices, None, X, plan=g.plan)
     assert float((y - y_planned).abs().max()) <= 1e-5 * float(y_planned.abs().max())
     ones = g.spmm(torch.ones(ND, F, device=dev))
@@ -149,14 +152,14 @@ def test_power_law_degrees_full_size(oracle, dev):
     lhs = (y.double() * W.double()).sum()
     rhs = (X.double() * g.spmm_t(W).double()).sum()
     assert abs(float(lhs - rhs)) <= 1e-6 * float((y.double().abs() * W.double().abs()).sum())
-    assert g.regular_t and g._S.sliced_t is not None  # source degrees are uniform: plain sliced backward
+    assert g.regular_t and (FORCED or g._S.sliced_t is not None)  # source degrees are uniform: plain sliced backward
     # the mirrored case: a graph whose SOURCE degrees are the power law (its transpose takes the split path)
     gt = ops.CSRGraph(src, dst, ND, NS)
     Xs = torch.randn(NS, F, generator=gen, device=dev)
     V = torch.randn(ND, F, generator=gen, device=dev)
     lhs = (gt.spmm(Xs).double() * V.double()).sum()
     dxs = gt.spmm_t(V)
-    assert gt._S.split_t is not None
+    assert FORCED or gt._S.split_t is not None
     rhs = (Xs.double() * dxs.double()).sum()
     assert abs(float(lhs - rhs)) <= 1e-6 * float((gt.spmm(Xs).double().abs() * V.double().abs()).sum())
 

@@ -28,6 +28,17 @@ def test_gcmc_layer(dev, name, fuse):
     C.case_gcmc_layer(dev, name, fuse)
 
 
+@pytest.mark.parametrize("name", ["shared_ini", "unshared"])
+def test_gcmc_layer_with_device_argument(dev, name):
+    """The reference's Net always passes device=args.device to its layers (model.py:19,40): the
+    fused relation path (f3) must engage in that configuration too, not only with device=None
+    (`case_gcmc_layer` asserts that the fused CSRs were built and used)."""
+    import torch
+
+    C.case_gcmc_layer(dev, name, True, device_arg=torch.device("cuda:0"))
+    C.case_gcmc_layer(dev, name, True, device_arg="cuda:0")
+
+
 @pytest.mark.parametrize("name", ["both", "simonly"])
 def test_fgcn(dev, name):
     C.case_fgcn(dev, name)

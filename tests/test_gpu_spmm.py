@@ -188,6 +188,29 @@ def test_out_of_range_row_is_reported(dev):
         ops.CSRGraph(ok_row, bad_col, 3, 4)
 
 
+@pytest.mark.parametrize("bad", [-1, 3 + 2 ** 10, 3 + 2 ** 20, 2 ** 31 - 1])
+@pytest.mark.parametrize("side", ["dst", "src"])
+def test_csrgraph_rejects_bad_ids_before_building_anything(dev, bad, side):
+    """a negative or aliasing id must surface as RuntimeError from CSRGraph itself — the
+    range flag is read before the launch plan is derived from the (then meaningless) indptr — and
+    the device must still be healthy afterwards."""
+    from dream_gnn_amd import ops
+
+    n_dst, n_src, E = 3, 5, 4000
+    g = torch.Generator().manual_seed(1)
+    dst = torch.randint(0, n_dst, (E,), generator=g, dtype=torch.int32)
+    src = torch.randint(0, n_src, (E,), generator=g, dtype=torch.int32)
+    (dst if side == "dst" else src)[E // 2] = bad
+    with pytest.raises(RuntimeError, match="out of range"):
+        ops.CSRGraph(dst.to(dev), src.to(dev), n_dst, n_src)
+    with pytest.raises(RuntimeError, match="out of range"):
+        ops.EdgePairs(src.to(dev), dst.to(dev), n_src, n_dst)
+    torch.cuda.synchronize()
+    ok = ops.CSRGraph(torch.zeros(4, dtype=torch.int32, device=dev), torch.arange(4, dtype=torch.int32, device=dev), 1, 4)
+    y = ok.spmm(torch.ones(4, 8, device=dev))
+    assert torch.equal(y.cpu(), torch.full((1, 8), 4.0))
+
+
 @pytest.mark.parametrize("Fa,Fb", [(128, 128), (16, 16), (8, 24), (5, 7), (341, 3)])
 def test_gather_concat_bit_exact_and_backward(oracle, dev, Fa, Fb):
     """(f2) decoder apply_edges(udf_u_mul_e): forward is pure copies -> bit-identical to the

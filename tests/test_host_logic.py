@@ -38,6 +38,16 @@ def test_gcmc_layer(name, fuse):
     C.case_gcmc_layer(CPU, name, fuse)
 
 
+@pytest.mark.parametrize("fuse", [True, False])
+def test_gcmc_layer_dropout_draw_order(fuse):
+    """Dropout on (p = 0.3): the reference run drew one (N_src, 1) mask per relation, in the graph's
+    canonical (sorted, DGL-style) relation order, then the two layer-level masks.  On the CPU the
+    torch RNG stream is the reference's, so equal outputs mean equal draw order and placement —
+    in the fused path and in the per-slice path alike.  (Order is relative to the stand-in's
+    HeteroGraphConv; DGL itself is absent — parity unpinned.)"""
+    C.case_gcmc_layer(CPU, "shared_dropout", fuse, dropout_rate=0.3, seed=31337)
+
+
 @pytest.mark.parametrize("name", ["both", "simonly"])
 def test_fgcn(name):
     C.case_fgcn(CPU, name)
