@@ -6,6 +6,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "dgmi.h"
+
 namespace dgmi {
 
 // ---- SpMM plan (dgmi_plan.hip): int32 words on the device --------------------------------
@@ -110,6 +112,29 @@ struct SlicedArgs {
 };
 hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s);
 
+// Row-owned, slice-swept SpMM (dgmi_owned.hip): geometry, layout build, product.
+using OwnedGeom = ::dgmi_owned_geom;
+bool owned_geometry(int64_t n_rows, int64_t n_cols, int64_t F, int blocks_per_cu, int n_slices, OwnedGeom* out);
+hipError_t csr_owned_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E, int64_t n_rows,
+                                  int64_t n_cols, const OwnedGeom& gm, int32_t* seg_ptr, uint32_t* words,
+                                  int32_t* eid, void* workspace, size_t* workspace_bytes, hipStream_t s);
+size_t owned_progress_bytes(const OwnedGeom& gm);
+struct OwnedArgs {
+  const int32_t* seg_ptr;  // n_groups * n_slices + 1
+  const uint32_t* words;
+  const float* vals;       // nullable, layout order
+  const float* X;
+  int64_t ldx;
+  const float* src_scale;  // nullable
+  const float* dst_scale;  // nullable
+  float* Y;
+  int64_t ldy;
+  int64_t n_dst, n_src, F;
+  OwnedGeom geom;
+  uint32_t* progress;      // nullable: owned_progress_bytes() of pacing counters (zeroed by the launch)
+};
+hipError_t spmm_owned_f32(const OwnedArgs& a, hipStream_t s);
+
 // out[e] = cat(A[src[e]], B[dst[e]])   (dgmi_edge.hip)
 hipError_t gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
                              int64_t lda, int64_t Fa, const float* B, int64_t ldb, int64_t Fb,
@@ -127,5 +152,9 @@ hipError_t random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float*
 
 hipError_t gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,
                       hipStream_t s);
+
+// Measurement probe (dgmi_probe.hip): hash-indexed whole-row gathers in the product kernels' shape.
+hipError_t probe_row_gather(const float* table, int64_t n_rows, int64_t F, int64_t groups, int64_t per_group,
+                            int64_t window, int per_xcd, float* out, hipStream_t s);
 
 }  // namespace dgmi

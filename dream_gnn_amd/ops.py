@@ -284,6 +284,77 @@ class SlicedCSR:
         return out
 
 
+class OwnedCSR:
+    """Row-owned, slice-swept layout (``dgmi_csr_owned_from_coo_i32`` / ``dgmi_spmm_owned_f32``):
+    every lane group of the launch owns a few destination rows (running sums in LDS) and sweeps
+    the source slices in order; no partial planes, Y written once.  The layout depends on the
+    feature-width class (lanes per row) through its geometry, so it is built for one ``F``."""
+
+    def __init__(self, dst, src, n_dst, n_src, F: int = 128, vals=None, blocks_per_cu: int = 0, n_slices: int = 0,
+                 paced: bool = True):
+        dev = _require_device(dst, src, vals)
+        self.paced = paced
+        self.n_dst, self.n_src, self.F = int(n_dst), int(n_src), int(F)
+        self.geom = _lib.OwnedGeom()
+        rc = _L.dgmi_owned_geometry(self.n_dst, self.n_src, self.F, blocks_per_cu, n_slices, ctypes.byref(self.geom))
+        if rc:
+            raise RuntimeError("shape not eligible for the row-owned kernel (needs F %% 4 == 0, F <= 256, "
+                               "n_src < 2^27): n_dst=%d n_src=%d F=%d" % (self.n_dst, self.n_src, self.F))
+        E = dst.shape[0]
+        with _guard(dev):
+            self.seg_ptr = torch.empty(self.geom.n_groups * self.geom.n_slices + 1, dtype=torch.int32, device=dev)
+            self.words = torch.empty(E, dtype=torch.int32, device=dev)  # src | local_row << 27 (bit pattern)
+            self.eid = torch.empty(E, dtype=torch.int32, device=dev)
+            need = ctypes.c_size_t(0)
+            _lib.check(_L.dgmi_csr_owned_from_coo_i32(_ptr(dst), _ptr(src), E, self.n_dst, self.n_src,
+                                                      ctypes.byref(self.geom), None, None, None, None,
+                                                      ctypes.byref(need), None), "dgmi_csr_owned_from_coo_i32(size query)")
+            ws = torch.empty(max(int(need.value), 256), dtype=torch.uint8, device=dev)
+            have = ctypes.c_size_t(ws.numel())
+            _lib.check(_L.dgmi_csr_owned_from_coo_i32(_ptr(dst), _ptr(src), E, self.n_dst, self.n_src,
+                                                      ctypes.byref(self.geom), _ptr(self.seg_ptr), _ptr(self.words),
+                                                      _ptr(self.eid), _ptr(ws), ctypes.byref(have), _stream(dev)),
+                       "dgmi_csr_owned_from_coo_i32")
+            self._flag = ws[:4].view(torch.int32).clone()
+            # pacing counters: scratch owned by the layout, reused by every product on it (products on
+            # one layout are stream-ordered; the launch zeroes it)
+            self._pbytes = int(_L.dgmi_spmm_owned_progress_bytes(ctypes.byref(self.geom)))
+            self._progress = torch.empty(max(self._pbytes, 16), dtype=torch.uint8, device=dev)
+        self.vals = None if vals is None else gather_f32(vals, self.eid)
+
+    def fits(self, F: int) -> bool:
+        """Whether a product of width F can run on this layout (same lanes-per-row class)."""
+        return F % 4 == 0 and 0 < F <= 4 * self.geom.lanes_per_row
+
+    _DEFAULT = object()
+
+    def spmm(self, X, src_scale=None, dst_scale=None, out=None, vals=_DEFAULT):
+        vals = self.vals if vals is OwnedCSR._DEFAULT else vals
+        dev = self.seg_ptr.device
+        if not X.is_cuda or X.device != dev:
+            _require_device(self.seg_ptr, X)
+        X, n_x, F, ldx = _prep_dense(X)
+        if n_x != self.n_src:
+            raise RuntimeError("X has %d rows, the graph has %d source nodes" % (n_x, self.n_src))
+        if not self.fits(F):
+            raise RuntimeError("layout was built for F=%d (lanes per row %d); got F=%d"
+                               % (self.F, self.geom.lanes_per_row, F))
+        src_scale = _prep_scale(src_scale, self.n_src, "src_scale")
+        dst_scale = _prep_scale(dst_scale, self.n_dst, "dst_scale")
+        if out is None:
+            out = torch.empty((self.n_dst, F), dtype=torch.float32, device=dev)
+        elif out.dtype != torch.float32 or tuple(out.shape) != (self.n_dst, F) or not out.is_contiguous():
+            raise RuntimeError("out must be a contiguous float32 (%d, %d) tensor" % (self.n_dst, F))
+        with _guard(dev):
+            rc = _L.dgmi_spmm_owned_f32(self.seg_ptr.data_ptr(), self.words.data_ptr(), _ptr(vals), X.data_ptr(), ldx,
+                                        _ptr(src_scale), _ptr(dst_scale), out.data_ptr(), F, self.n_dst, self.n_src, F,
+                                        ctypes.byref(self.geom), self._progress.data_ptr() if self.paced else None,
+                                        self._pbytes, _stream(dev))
+            if rc:
+                _lib.check(rc, "dgmi_spmm_owned_f32")
+        return out
+
+
 # XCD-local path is used when the gather table is a few L2s large (8 XCDs x 4 MiB): below, X is
 # L2-hot anyway; far above, a 1/8 slice no longer fits an L2 and the plane traffic is pure cost.
 # Measured on MI355X (tools/explore.py slicedcap, 10 M edges, F=128): sliced/planned time ratio

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 7
+#define DGMI_ABI_VERSION 8
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -189,6 +189,59 @@ DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices,
                                   size_t planes_bytes, dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
+ * Row-owned, slice-swept SpMM: the same product (B-i / B-ii) with no partial planes.
+ *
+ * Every lane group of the launch owns a few destination rows, keeps their running sums in LDS and
+ * sweeps the source slices of X in order, so that at any time an XCD's gathers fall into one or
+ * two L2-sized slices; Y is written once.  All workgroups are co-resident (grid = #CUs x
+ * blocks_per_cu) — a speed assumption only.  In-row order: slice by slice, input order inside a
+ * slice (deterministic; not the plain CSR's order).
+ *
+ *   dgmi_owned_geometry          host-only: how rows map to groups for (n_rows, n_cols, F).
+ *                                blocks_per_cu <= 0 and n_slices <= 0 pick the defaults (5 and
+ *                                ceil(n_cols * 4F / 3200 KiB)).  Returns DGMI_ERR_INVALID_ARG when the
+ *                                shape is not eligible: F % 4 != 0, F > 256 or n_cols >= 2^27.
+ *   dgmi_csr_owned_from_coo_i32  workspace protocol and error flag as dgmi_csr_from_coo_i32.
+ *                                seg_ptr[geom.n_groups * geom.n_slices + 1]: first edge of (group,
+ *                                slice); words[E] = src | local_row << 27; eid[E] maps layout
+ *                                positions to the caller's edge order.
+ *   dgmi_spmm_owned_f32          vals (nullable) are in layout order; requires ldx % 4 == 0,
+ *                                ldy % 4 == 0, 16-B aligned X / Y and the geometry the layout was
+ *                                built with (same F class: geom.lanes_per_row covers F / 4).
+ *                                progress (nullable): dgmi_spmm_owned_progress_bytes(geom) bytes of
+ *                                device scratch; when given (and 1 < n_slices <= lanes_per_row) the
+ *                                groups pace each other slice by slice through counters in it —
+ *                                a speed aid (L2 residency of the live slice), zeroed by the call.
+ */
+typedef struct dgmi_owned_geom {
+  int32_t n_groups;         /* rounds * groups_per_round */
+  int32_t n_slices;
+  int32_t rmax;             /* most rows a group owns (<= 32) */
+  int32_t rows_lo;          /* n_rows / n_groups */
+  int32_t extra;            /* n_rows % n_groups: the first `extra` groups own rows_lo + 1 rows */
+  int32_t slice_width;      /* source ids per slice */
+  int32_t groups_per_round; /* #CUs * blocks_per_cu * groups per block */
+  int32_t rounds;
+  int32_t lanes_per_row;    /* 8 / 16 / 32 / 64 lanes, 16 B each */
+  int32_t blocks;           /* grid size: #CUs * blocks_per_cu */
+  int32_t lds_bytes;        /* dynamic LDS per block */
+  int32_t reserved;
+} dgmi_owned_geom;
+
+DGMI_API int dgmi_owned_geometry(int64_t n_rows, int64_t n_cols, int64_t F, int32_t blocks_per_cu,
+                                 int32_t n_slices, dgmi_owned_geom* geom /* host */);
+DGMI_API int dgmi_csr_owned_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
+                                         int64_t n_rows, int64_t n_cols, const dgmi_owned_geom* geom /* host */,
+                                         int32_t* seg_ptr, uint32_t* words, int32_t* eid, void* workspace,
+                                         size_t* workspace_bytes, dgmi_stream_t stream);
+DGMI_API size_t dgmi_spmm_owned_progress_bytes(const dgmi_owned_geom* geom /* host */);
+DGMI_API int dgmi_spmm_owned_f32(const int32_t* seg_ptr, const uint32_t* words, const float* vals,
+                                 const float* X, int64_t ldx, const float* src_scale,
+                                 const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
+                                 int64_t n_src, int64_t F, const dgmi_owned_geom* geom /* host */,
+                                 void* progress, size_t progress_bytes, dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
  * (f2) Per-edge gather-concat: out[e, 0:Fa] = A[src[e], :], out[e, Fa:Fa+Fb] = B[dst[e], :].
  * Replaces graph.apply_edges(udf_u_mul_e) of the MLP decoder (layers.py:364,378-379:
  * th.cat([edges.src['h'], edges.dst['h']], 1)), which DGL runs as two index_selects and a
@@ -227,6 +280,19 @@ DGMI_API size_t dgmi_random_subset_workspace_bytes(void);
 DGMI_API int dgmi_random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask,
                                          void* workspace, size_t workspace_bytes,
                                          dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
+ * Measurement probe (bench.py; not part of the product path): `groups` lane groups each gather
+ * `per_group` pseudo-random whole rows of `table` (n_rows x F fp32, contiguous) in exactly the
+ * SpMM kernels' access shape — F/4 lanes x 16 B per row, 8 gathers in flight per lane, sums in
+ * registers — with hash-generated row ids, and write one F-wide row each to out[groups x F].
+ * Rows are drawn from a window of `window` rows; per_xcd != 0 gives workgroup b the window
+ * number b % 8 (each XCD gathers from its own L2-sized part of the table).  Bytes gathered =
+ * groups * per_group * 4F.  Requires F % 4 == 0, F <= 256, 1 <= window <= n_rows.
+ */
+DGMI_API int dgmi_probe_row_gather_f32(const float* table, int64_t n_rows, int64_t F, int64_t groups,
+                                       int64_t per_group, int64_t window, int32_t per_xcd, float* out,
+                                       dgmi_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -116,6 +116,30 @@ def csr_sliced_from_coo(row, col, n_rows, n_cols, n_slices):
     return np.cumsum(segptr).astype(np.int32), col[order].astype(np.int32), order.astype(np.int32)
 
 
+def csr_owned_from_coo(row, col, n_rows, n_cols, geom):
+    """Row-owned layout of ``dgmi_csr_owned_from_coo_i32`` (dream_gnn_amd/csrc/dgmi_owned.hip):
+    rows are dealt evenly over ``n_groups`` lane groups (the first ``extra`` own ``rows_lo + 1``),
+    edges sorted stably by ``(group(row) * n_slices + slice(col)) * rmax + local_row``.
+    ``geom``: anything with the fields of ``dgmi_owned_geom``.  Returns (seg_ptr, words, eid) with
+    ``seg_ptr[g * n_slices + s]`` the first edge of (group g, slice s)."""
+    row = np.asarray(row, np.int64)
+    col = np.asarray(col, np.int64)
+    G, S, rmax, lo, extra, width = (int(getattr(geom, k)) for k in
+                                    ("n_groups", "n_slices", "rmax", "rows_lo", "extra", "slice_width"))
+    big = extra * (lo + 1)
+    in_big = row < big
+    q = (row - big) // max(lo, 1)
+    g = np.where(in_big, row // (lo + 1), extra + q)
+    lrow = np.where(in_big, row - (row // (lo + 1)) * (lo + 1), (row - big) - q * lo)
+    sl = np.minimum(col // width, S - 1)
+    key = (g * S + sl) * rmax + lrow
+    order = np.argsort(key, kind="stable")
+    seg_ptr = np.zeros(G * S + 1, np.int64)
+    np.add.at(seg_ptr, g * S + sl + 1, 1)
+    words = (col[order] | (lrow[order] << 27)).astype(np.uint32)
+    return np.cumsum(seg_ptr).astype(np.int32), words, order.astype(np.int32)
+
+
 def spmm_csr(indptr, indices, vals, X, src_scale=None, dst_scale=None, threads=1, acc="f32", validate=True):
     """``Y = diag(dst_scale) A diag(src_scale) X`` over a CSR; ``vals=None`` is
     ``update_all(copy_u, sum)`` (layers.py:229-232), else ``th.spmm`` (layers.py:312).

@@ -299,6 +299,87 @@ def test_xcd_sliced_edge_cases(oracle, dev):
     assert np.abs(y - y64).max() <= 1e-5 * np.abs(y64).max()
 
 
+@pytest.mark.parametrize("F", [4, 32, 64, 128, 256])
+@pytest.mark.parametrize("mode", ["copy_u", "all"])
+@pytest.mark.parametrize("shape", [(203, 157, 7000, 0), (203, 157, 7000, 5), (9, 1000, 4000, 3), (40, 30, 0, 0)])
+def test_row_owned_spmm_vs_oracle(oracle, dev, F, mode, shape):
+    """The row-owned, slice-swept path: layout bit-exact vs its numpy restatement (group pointers,
+    packed edge words, eid), product within 1e-5 of the f64 oracle, every row (fewer rows than lane
+    groups here: most groups own nothing, the others one row)."""
+    from dream_gnn_amd import ops
+
+    n_dst, n_src, E, n_slices = shape
+    rng = np.random.default_rng(F + n_dst + n_slices)
+    dst, src = _rand_graph(rng, n_dst, n_src, E) if E else (np.zeros(0, np.int32), np.zeros(0, np.int32))
+    X = rng.standard_normal((n_src, F)).astype(np.float32)
+    vals = rng.standard_normal(E).astype(np.float32) if mode == "all" else None
+    ss = rng.uniform(0.1, 1.0, n_src).astype(np.float32) if mode == "all" else None
+    ds = rng.uniform(0.1, 1.0, n_dst).astype(np.float32) if mode == "all" else None
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    ow = ops.OwnedCSR(t(dst), t(src), n_dst, n_src, F=F, vals=t(vals), n_slices=n_slices)
+    assert int(ow._flag.item()) == 0
+    seg_ptr, words, eid = oracle.csr_owned_from_coo(dst, src, n_dst, n_src, ow.geom)
+    assert np.array_equal(ow.seg_ptr.cpu().numpy(), seg_ptr)
+    assert np.array_equal(ow.words.cpu().numpy().view(np.uint32), words)
+    assert np.array_equal(ow.eid.cpu().numpy(), eid)
+    y = ow.spmm(t(X), t(ss), t(ds)).cpu().numpy()
+    ip, ix, e0 = oracle.csr_from_coo(dst, src, n_dst)
+    v0 = None if vals is None else vals[e0]
+    y64 = oracle.spmm_csr(ip, ix, v0, X, ss, ds, acc="f64")
+    yabs = oracle.spmm_csr(ip, ix, v0, X, ss, ds, acc="abs")
+    assert np.all(np.abs(y - y64) <= RTOL * yabs + 1e-30)
+    assert np.abs(y - y64).max() <= RTOL * max(np.abs(y64).max(), 1e-30)
+    assert np.all(y[np.diff(ip) == 0] == 0)
+    assert np.array_equal(y, ow.spmm(t(X), t(ss), t(ds)).cpu().numpy())  # reproducible
+
+
+@pytest.mark.parametrize("n_dst,F", [(100_003, 128), (70_001, 256), (170_003, 64)])
+def test_row_owned_many_rows_and_rounds(oracle, dev, n_dst, F):
+    """More destination rows than one sweep's LDS holds (-> several rounds per group), uneven
+    rows per group, long and empty rows, every row against the f64 oracle."""
+    from dream_gnn_amd import ops
+
+    rng = np.random.default_rng(n_dst)
+    n_src, E = 4_001, 600_000
+    dst = rng.integers(0, n_dst, E).astype(np.int32)
+    dst[:20_000] = 77  # one long row
+    dst[dst == 5] = 6  # an empty row
+    src = rng.integers(0, n_src, E).astype(np.int32)
+    X = rng.standard_normal((n_src, F)).astype(np.float32)
+    vals = rng.standard_normal(E).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ow = ops.OwnedCSR(t(dst), t(src), n_dst, n_src, F=F, vals=t(vals), n_slices=7)
+    assert ow.geom.rounds >= 2 and ow.geom.extra > 0
+    seg_ptr, words, eid = oracle.csr_owned_from_coo(dst, src, n_dst, n_src, ow.geom)
+    assert np.array_equal(ow.seg_ptr.cpu().numpy(), seg_ptr)
+    assert np.array_equal(ow.words.cpu().numpy().view(np.uint32), words) and np.array_equal(ow.eid.cpu().numpy(), eid)
+    y = ow.spmm(t(X)).cpu().numpy()
+    ip, ix, e0 = oracle.csr_from_coo(dst, src, n_dst)
+    y64 = oracle.spmm_csr(ip, ix, vals[e0], X, acc="f64")
+    yabs = oracle.spmm_csr(ip, ix, vals[e0], X, acc="abs")
+    assert np.all(np.abs(y - y64) <= RTOL * yabs + 1e-30)
+    assert np.all(y[5] == 0)
+    # unweighted: A @ ones = degree, exactly
+    ones = ow.spmm(torch.ones(n_src, F, device=dev), vals=None).cpu().numpy()
+    assert np.array_equal(ones[:, 0], np.diff(ip).astype(np.float32)) and np.array_equal(ones[:, 0], ones[:, F - 1])
+
+
+def test_row_owned_rejects_ineligible_shapes_and_bad_ids(dev):
+    from dream_gnn_amd import ops
+
+    z = torch.zeros(4, dtype=torch.int32, device=dev)
+    for F in (6, 260, 344):
+        with pytest.raises(RuntimeError, match="not eligible"):
+            ops.OwnedCSR(z, z, 5, 3, F=F)
+    ow = ops.OwnedCSR(z, z, 5, 3, F=128)
+    with pytest.raises(RuntimeError):
+        ow.spmm(torch.randn(3, 256, device=dev))  # wider than the layout's lanes per row
+    assert torch.equal(ow.spmm(torch.ones(3, 64, device=dev)), torch.tensor([4.0] + [0.0] * 4, device=dev)[:, None].expand(5, 64))
+    bad = torch.tensor([0, 9, 1, -1], dtype=torch.int32, device=dev)
+    assert int(ops.OwnedCSR(bad, z, 5, 3, F=128)._flag.item()) == 1  # reported, arrays stay in bounds
+    assert int(ops.OwnedCSR(z, bad, 5, 3, F=128)._flag.item()) == 1
+
+
 @pytest.mark.skipif(bool(__import__("os").environ.get("DGMI_FORCE_KERNEL")), reason="kernel choice is forced")
 def test_csrgraph_picks_sliced_only_when_profitable(dev):
     from dream_gnn_amd import ops
