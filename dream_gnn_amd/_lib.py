@@ -13,43 +13,28 @@ import torch  # noqa: F401  -- must come first: libdgmi.so binds to the HIP runt
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgmi.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # name -> (restype, argtypes); mirrors include/dgmi.h one to one.
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
 
 
-class OwnedGeom(ctypes.Structure):
-    """``dgmi_owned_geom`` (include/dgmi.h): how destination rows map to the lane groups of the
-    row-owned kernel.  Host-side plain data."""
-
-    _fields_ = [(n, ctypes.c_int32) for n in
-                ("n_groups", "n_slices", "rmax", "rows_lo", "extra", "slice_width", "groups_per_round", "rounds",
-                 "lanes_per_row", "blocks", "lds_bytes", "reserved")]
-
-
-_geomp = ctypes.POINTER(OwnedGeom)
 SIGNATURES = {
     "dgmi_abi_version": (ctypes.c_int, []),
     "dgmi_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "dgmi_device_ok": (ctypes.c_int, []),
     "dgmi_csr_from_coo_i32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp,
                                              ctypes.POINTER(ctypes.c_size_t), _vp]),
-    "dgmi_spmm_csr_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "dgmi_spmm_csr_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp, _vp, _vp, _i64, _i64,
+                                         _i64, _i64, _vp]),
     "dgmi_gather_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "dgmi_gather_concat_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "dgmi_csr_sliced_from_coo_i32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, ctypes.c_int32, _vp, _vp, _vp, _vp,
                                                     ctypes.POINTER(ctypes.c_size_t), _vp]),
     "dgmi_spmm_sliced_planes_bytes": (ctypes.c_size_t, [_i64, ctypes.c_int32, _i64]),
-    "dgmi_spmm_sliced_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
-                                            ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
-    "dgmi_owned_geometry": (ctypes.c_int, [_i64, _i64, _i64, ctypes.c_int32, ctypes.c_int32, _geomp]),
-    "dgmi_csr_owned_from_coo_i32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _geomp, _vp, _vp, _vp, _vp,
-                                                   ctypes.POINTER(ctypes.c_size_t), _vp]),
-    "dgmi_spmm_owned_progress_bytes": (ctypes.c_size_t, [_geomp]),
-    "dgmi_spmm_owned_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _geomp, _vp,
-                                           ctypes.c_size_t, _vp]),
+    "dgmi_spmm_sliced_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp, _vp, _vp, _i64, _i64,
+                                            _i64, _i64, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
     "dgmi_probe_row_gather_f32": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int32, _vp, _vp]),
     "dgmi_gather_add_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "dgmi_random_subset_workspace_bytes": (ctypes.c_size_t, []),
@@ -59,8 +44,11 @@ SIGNATURES = {
     "dgmi_spmm_partials_bytes": (ctypes.c_size_t, [_i64, ctypes.c_int32, _i64]),
     "dgmi_spmm_plan_build": (ctypes.c_int, [_vp, _i64, _i64, ctypes.c_int32, _vp, ctypes.c_size_t, _vp,
                                             ctypes.POINTER(ctypes.c_size_t), _vp]),
-    "dgmi_spmm_csr_planned_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
-                                                 _i64, ctypes.c_int32, _vp, _vp, ctypes.c_size_t, _vp]),
+    "dgmi_spmm_csr_planned_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp, _vp, _vp, _i64,
+                                                 _i64, _i64, _i64, _i64, ctypes.c_int32, _vp, _vp, ctypes.c_size_t, _vp]),
+    "dgmi_random_subset_select": (ctypes.c_int, [_i64, _i64, ctypes.c_uint64, ctypes.c_uint32, _vp, _vp, ctypes.c_size_t,
+                                                 _vp]),
+    "dgmi_keep_mask_f32": (ctypes.c_int, [_vp, ctypes.c_int32, _i64, _vp, _vp]),
 }
 
 

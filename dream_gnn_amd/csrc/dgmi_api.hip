@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "dgmi.h"
+#include "dgmi_keep.h"
 #include "dgmi_kernels.h"
 
 namespace {
@@ -65,11 +66,17 @@ DGMI_API int dgmi_csr_from_coo_i32(const int32_t* row, const int32_t* col, int64
                                          workspace_bytes, as_stream(stream)));
 }
 
+static bool keep_args_ok(const int32_t* eid, const uint32_t* keep, int32_t n_keep) {
+  if (n_keep < 0 || n_keep > dgmi::kMaxKeepSegs) return false;
+  return n_keep == 0 || (eid != nullptr && keep != nullptr);
+}
+
 DGMI_API int dgmi_spmm_csr_f32(const int32_t* indptr, const int32_t* indices, const float* vals,
+                      const int32_t* eid, const uint32_t* keep, int32_t n_keep,
                       const float* X, int64_t ldx, const float* src_scale,
                       const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
                       int64_t n_src, int64_t F, dgmi_stream_t stream) {
-  if (n_dst < 0 || n_src < 0 || F < 0) return DGMI_ERR_INVALID_ARG;
+  if (n_dst < 0 || n_src < 0 || F < 0 || !keep_args_ok(eid, keep, n_keep)) return DGMI_ERR_INVALID_ARG;
   if (n_dst >= INT32_MAX || n_src >= INT32_MAX || F > INT32_MAX) return DGMI_ERR_TOO_LARGE;
   if (n_dst == 0 || F == 0) return DGMI_OK;
   if (indptr == nullptr || Y == nullptr) return DGMI_ERR_INVALID_ARG;
@@ -79,7 +86,7 @@ DGMI_API int dgmi_spmm_csr_f32(const int32_t* indptr, const int32_t* indices, co
   if (X == nullptr && n_src > 0) return DGMI_ERR_INVALID_ARG;
   if (static_cast<const void*>(X) == static_cast<const void*>(Y)) return DGMI_ERR_INVALID_ARG;
   dgmi::SpmmArgs a{indptr, indices, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F,
-                   nullptr, 0, 0, nullptr, 0};
+                   nullptr, 0, 0, nullptr, 0, eid, keep, n_keep};
   return from_hip(dgmi::spmm_csr_f32(a, as_stream(stream)));
 }
 
@@ -130,12 +137,14 @@ DGMI_API int dgmi_spmm_plan_build(const int32_t* indptr, int64_t n_rows, int64_t
 }
 
 DGMI_API int dgmi_spmm_csr_planned_f32(const int32_t* indptr, const int32_t* indices,
-                                       const float* vals, const float* X, int64_t ldx,
+                                       const float* vals, const int32_t* eid, const uint32_t* keep,
+                                       int32_t n_keep, const float* X, int64_t ldx,
                                        const float* src_scale, const float* dst_scale, float* Y,
                                        int64_t ldy, int64_t n_dst, int64_t n_src, int64_t F,
                                        int64_t nnz, int32_t chunk, const void* plan, void* partials,
                                        size_t partials_bytes, dgmi_stream_t stream) {
-  if (n_dst < 0 || n_src < 0 || F < 0 || nnz < 0 || !chunk_ok(chunk)) return DGMI_ERR_INVALID_ARG;
+  if (n_dst < 0 || n_src < 0 || F < 0 || nnz < 0 || !chunk_ok(chunk) || !keep_args_ok(eid, keep, n_keep))
+    return DGMI_ERR_INVALID_ARG;
   if (n_dst >= INT32_MAX || n_src >= INT32_MAX || F > INT32_MAX || nnz > INT32_MAX)
     return DGMI_ERR_TOO_LARGE;
   if (n_dst == 0 || F == 0) return DGMI_OK;
@@ -147,7 +156,7 @@ DGMI_API int dgmi_spmm_csr_planned_f32(const int32_t* indptr, const int32_t* ind
   if (partials_bytes < dgmi_spmm_partials_bytes(nnz, chunk, F)) return DGMI_ERR_WORKSPACE;
   dgmi::SpmmArgs a{indptr, indices, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F,
                    static_cast<const int32_t*>(plan), nnz, chunk, static_cast<float*>(partials),
-                   (F + 3) / 4 * 4};
+                   (F + 3) / 4 * 4, eid, keep, n_keep};
   return from_hip(dgmi::spmm_csr_f32(a, as_stream(stream)));
 }
 
@@ -201,11 +210,13 @@ DGMI_API size_t dgmi_spmm_sliced_planes_bytes(int64_t n_dst, int32_t n_slices, i
 }
 
 DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices, const float* vals,
+                                  const int32_t* eid, const uint32_t* keep, int32_t n_keep,
                                   const float* X, int64_t ldx, const float* src_scale,
                                   const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
                                   int64_t n_src, int64_t F, int32_t n_slices, void* planes,
                                   size_t planes_bytes, dgmi_stream_t stream) {
-  if (n_dst < 0 || n_src < 0 || F < 0 || n_slices < 1 || n_slices > 64) return DGMI_ERR_INVALID_ARG;
+  if (n_dst < 0 || n_src < 0 || F < 0 || n_slices < 1 || n_slices > 64 || !keep_args_ok(eid, keep, n_keep))
+    return DGMI_ERR_INVALID_ARG;
   if (n_dst >= INT32_MAX || n_src >= INT32_MAX || F > INT32_MAX) return DGMI_ERR_TOO_LARGE;
   if (n_dst == 0 || F == 0) return DGMI_OK;
   if (segptr == nullptr || Y == nullptr || planes == nullptr) return DGMI_ERR_INVALID_ARG;
@@ -217,82 +228,8 @@ DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices,
   if (static_cast<const void*>(X) == static_cast<const void*>(Y)) return DGMI_ERR_INVALID_ARG;
   if (planes_bytes < dgmi_spmm_sliced_planes_bytes(n_dst, n_slices, F)) return DGMI_ERR_WORKSPACE;
   dgmi::SlicedArgs a{segptr, indices, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F, n_slices,
-                     static_cast<float*>(planes), F, sliced_chunk_rows(n_dst, n_slices, F)};
+                     static_cast<float*>(planes), F, sliced_chunk_rows(n_dst, n_slices, F), eid, keep, n_keep};
   return from_hip(dgmi::spmm_sliced_f32(a, as_stream(stream)));
-}
-
-DGMI_API int dgmi_owned_geometry(int64_t n_rows, int64_t n_cols, int64_t F, int32_t blocks_per_cu,
-                                 int32_t n_slices, dgmi_owned_geom* geom) {
-  if (geom == nullptr || n_rows < 0 || n_cols < 0 || F < 0) return DGMI_ERR_INVALID_ARG;
-  if (n_rows >= INT32_MAX || n_cols >= INT32_MAX) return DGMI_ERR_TOO_LARGE;
-  return dgmi::owned_geometry(n_rows, n_cols, F, blocks_per_cu, n_slices, geom) ? DGMI_OK : DGMI_ERR_INVALID_ARG;
-}
-
-static bool geom_ok(const dgmi_owned_geom* g, int64_t n_rows, int64_t n_cols) {
-  if (g == nullptr || g->n_groups < 1 || g->n_slices < 1 || g->rmax < 1 || g->rmax > 32 || g->rows_lo < 0 ||
-      g->extra < 0 || g->slice_width < 1 || g->groups_per_round < 1 || g->rounds < 1 || g->blocks < 1 ||
-      g->lds_bytes < 0 || g->lds_bytes > 64 * 1024)
-    return false;
-  if (g->lanes_per_row != 8 && g->lanes_per_row != 16 && g->lanes_per_row != 32 && g->lanes_per_row != 64)
-    return false;
-  const int64_t gpb = 4 * (64 / g->lanes_per_row);
-  if ((int64_t)g->groups_per_round != (int64_t)g->blocks * gpb) return false;
-  if ((int64_t)g->n_groups != (int64_t)g->rounds * g->groups_per_round) return false;
-  if ((int64_t)g->n_groups * g->rows_lo + g->extra != n_rows || g->extra >= g->n_groups) return false;
-  if (g->rmax != g->rows_lo + (g->extra ? 1 : 0)) return false;
-  if ((int64_t)g->slice_width * g->n_slices < n_cols) return false;
-  if (gpb * g->rmax * g->lanes_per_row * 16 > g->lds_bytes) return false;
-  return (int64_t)g->n_groups * g->n_slices * g->rmax < INT32_MAX;
-}
-
-DGMI_API int dgmi_csr_owned_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E, int64_t n_rows,
-                                         int64_t n_cols, const dgmi_owned_geom* geom, int32_t* seg_ptr,
-                                         uint32_t* words, int32_t* eid, void* workspace,
-                                         size_t* workspace_bytes, dgmi_stream_t stream) {
-  if (E < 0 || n_rows <= 0 || n_cols <= 0 || workspace_bytes == nullptr) return DGMI_ERR_INVALID_ARG;
-  if (E > INT32_MAX || n_rows >= INT32_MAX || n_cols >= (1 << 27)) return DGMI_ERR_TOO_LARGE;
-  if (!geom_ok(geom, n_rows, n_cols)) return DGMI_ERR_INVALID_ARG;
-  if (workspace != nullptr) {
-    if (seg_ptr == nullptr) return DGMI_ERR_INVALID_ARG;
-    if (E > 0 && (row == nullptr || col == nullptr || words == nullptr || eid == nullptr))
-      return DGMI_ERR_INVALID_ARG;
-  }
-  size_t need = 0;
-  if (dgmi::csr_owned_from_coo_i32(row, col, E, n_rows, n_cols, *geom, seg_ptr, words, eid, nullptr, &need,
-                                   as_stream(stream)) != hipSuccess)
-    return DGMI_ERR_LAUNCH;
-  if (workspace == nullptr) {
-    *workspace_bytes = need;
-    return DGMI_OK;
-  }
-  if (*workspace_bytes < need) return DGMI_ERR_WORKSPACE;
-  return from_hip(dgmi::csr_owned_from_coo_i32(row, col, E, n_rows, n_cols, *geom, seg_ptr, words, eid, workspace,
-                                               workspace_bytes, as_stream(stream)));
-}
-
-DGMI_API size_t dgmi_spmm_owned_progress_bytes(const dgmi_owned_geom* geom) {
-  if (geom == nullptr || geom->rounds < 1 || geom->n_slices < 1) return 0;
-  return dgmi::owned_progress_bytes(*geom);
-}
-
-DGMI_API int dgmi_spmm_owned_f32(const int32_t* seg_ptr, const uint32_t* words, const float* vals, const float* X,
-                                 int64_t ldx, const float* src_scale, const float* dst_scale, float* Y,
-                                 int64_t ldy, int64_t n_dst, int64_t n_src, int64_t F,
-                                 const dgmi_owned_geom* geom, void* progress, size_t progress_bytes,
-                                 dgmi_stream_t stream) {
-  if (n_dst < 0 || n_src < 0 || F < 0) return DGMI_ERR_INVALID_ARG;
-  if (n_dst >= INT32_MAX || n_src >= (1 << 27)) return DGMI_ERR_TOO_LARGE;
-  if (n_dst == 0 || F == 0) return DGMI_OK;
-  if (seg_ptr == nullptr || Y == nullptr || X == nullptr) return DGMI_ERR_INVALID_ARG;
-  if (!geom_ok(geom, n_dst, n_src)) return DGMI_ERR_INVALID_ARG;
-  if (progress != nullptr && progress_bytes < dgmi::owned_progress_bytes(*geom)) return DGMI_ERR_WORKSPACE;
-  if (ldx < F || ldy < F || F % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || F > 4 * (int64_t)geom->lanes_per_row)
-    return DGMI_ERR_INVALID_ARG;
-  if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(Y) & 15)) return DGMI_ERR_INVALID_ARG;
-  if (static_cast<const void*>(X) == static_cast<const void*>(Y)) return DGMI_ERR_INVALID_ARG;
-  dgmi::OwnedArgs a{seg_ptr, words, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F, *geom,
-                    static_cast<uint32_t*>(progress)};
-  return from_hip(dgmi::spmm_owned_f32(a, as_stream(stream)));
 }
 
 DGMI_API int dgmi_gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
@@ -329,6 +266,23 @@ DGMI_API int dgmi_random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed,
   if (mask == nullptr || workspace == nullptr) return DGMI_ERR_INVALID_ARG;
   if (workspace_bytes < dgmi::random_subset_workspace_bytes()) return DGMI_ERR_WORKSPACE;
   return from_hip(dgmi::random_subset_mask_f32(E, keep, seed, mask, workspace, as_stream(stream)));
+}
+
+DGMI_API int dgmi_random_subset_select(int64_t E, int64_t keep, uint64_t seed, uint32_t e_offset, uint32_t* desc,
+                                      void* workspace, size_t workspace_bytes, dgmi_stream_t stream) {
+  if (E < 0 || keep < 0 || keep > E || desc == nullptr) return DGMI_ERR_INVALID_ARG;
+  if (E > INT32_MAX || (uint64_t)e_offset + (uint64_t)E > (uint64_t)INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (workspace == nullptr) return DGMI_ERR_INVALID_ARG;
+  if (workspace_bytes < dgmi::random_subset_workspace_bytes()) return DGMI_ERR_WORKSPACE;
+  return from_hip(dgmi::random_subset_select(E, keep, seed, e_offset, desc, workspace, as_stream(stream)));
+}
+
+DGMI_API int dgmi_keep_mask_f32(const uint32_t* keep, int32_t n_keep, int64_t E, float* mask, dgmi_stream_t stream) {
+  if (E < 0 || n_keep < 0 || n_keep > dgmi::kMaxKeepSegs || (n_keep > 0 && keep == nullptr)) return DGMI_ERR_INVALID_ARG;
+  if (E > INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (E == 0) return DGMI_OK;
+  if (mask == nullptr) return DGMI_ERR_INVALID_ARG;
+  return from_hip(dgmi::keep_mask_f32(keep, n_keep, E, mask, as_stream(stream)));
 }
 
 DGMI_API int dgmi_gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,

@@ -6,8 +6,6 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#include "dgmi.h"
-
 namespace dgmi {
 
 // ---- SpMM plan (dgmi_plan.hip): int32 words on the device --------------------------------
@@ -73,6 +71,11 @@ struct SpmmArgs {
   int64_t chunk;
   float* partials;
   int64_t ldp;
+  // edge dropout applied on the fly (dgmi_keep.h): n_keep > 0 -> edge p survives iff
+  // keep(eid[p]) under the n_keep descriptions in `keep` (device, 8 words each)
+  const int32_t* eid;
+  const void* keep;
+  int n_keep;
 };
 
 // Y = diag(dst_scale) A diag(src_scale) X   (dgmi_spmm.hip)
@@ -109,31 +112,11 @@ struct SlicedArgs {
   float* planes;           // n_slices * min(n_dst, chunk_rows) * ldp floats of scratch
   int64_t ldp;
   int64_t chunk_rows;      // destination rows per launch pair (planes stay Infinity-Cache resident)
+  const int32_t* eid;      // edge dropout on the fly, as SpmmArgs
+  const void* keep;
+  int n_keep;
 };
 hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s);
-
-// Row-owned, slice-swept SpMM (dgmi_owned.hip): geometry, layout build, product.
-using OwnedGeom = ::dgmi_owned_geom;
-bool owned_geometry(int64_t n_rows, int64_t n_cols, int64_t F, int blocks_per_cu, int n_slices, OwnedGeom* out);
-hipError_t csr_owned_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E, int64_t n_rows,
-                                  int64_t n_cols, const OwnedGeom& gm, int32_t* seg_ptr, uint32_t* words,
-                                  int32_t* eid, void* workspace, size_t* workspace_bytes, hipStream_t s);
-size_t owned_progress_bytes(const OwnedGeom& gm);
-struct OwnedArgs {
-  const int32_t* seg_ptr;  // n_groups * n_slices + 1
-  const uint32_t* words;
-  const float* vals;       // nullable, layout order
-  const float* X;
-  int64_t ldx;
-  const float* src_scale;  // nullable
-  const float* dst_scale;  // nullable
-  float* Y;
-  int64_t ldy;
-  int64_t n_dst, n_src, F;
-  OwnedGeom geom;
-  uint32_t* progress;      // nullable: owned_progress_bytes() of pacing counters (zeroed by the launch)
-};
-hipError_t spmm_owned_f32(const OwnedArgs& a, hipStream_t s);
 
 // out[e] = cat(A[src[e]], B[dst[e]])   (dgmi_edge.hip)
 hipError_t gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
@@ -147,6 +130,11 @@ hipError_t gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, con
 
 // mask[e] = 1 for a uniformly random subset of exactly `keep` of the E edges (dgmi_select.hip)
 size_t random_subset_workspace_bytes();
+// the 8-word description (dgmi_keep.h) of a uniformly random subset of exactly `keep` of E edges
+hipError_t random_subset_select(int64_t E, int64_t keep, uint64_t seed, uint32_t e_offset, void* seg_out,
+                                void* workspace, hipStream_t s);
+// mask[e] = keep(e) under `n_seg` descriptions, e in [0, E)
+hipError_t keep_mask_f32(const void* table, int n_seg, int64_t E, float* mask, hipStream_t s);
 hipError_t random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask, void* workspace,
                                   hipStream_t s);
 

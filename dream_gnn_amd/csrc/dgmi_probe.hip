@@ -30,7 +30,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 // Each LPR-lane group gathers `per_group` pseudo-random rows of `table` (n_rows x F, ld = F) and
 // writes their sum to out[group].  `window`: rows are drawn from [base, base + window) where base
 // depends on blockIdx % 8 when `per_xcd` — every XCD then works on its own window of the table
-// (the L2-local regime of the sliced / row-owned kernels).
+// (the L2-local regime of the XCD-sliced kernel).
 template <int LPR>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void probe_row_gather_kernel(
     const float* __restrict__ table, int64_t n_rows, int F, int64_t groups, int64_t per_group, int64_t window,

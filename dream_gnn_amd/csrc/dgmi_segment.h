@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dgmi_keep.h"
+
 namespace dgmi {
 namespace {
 
@@ -31,7 +33,10 @@ __device__ __forceinline__ void tree_sum(float4 (&v)[kUnroll], int n_live) {
 
 // One batch of up to 64 edges whose ids/weights sit one-per-lane in
 // (my_idx, my_w).  FULL: all 64 are valid, no predication in the loop.
-template <int LPR, bool WEIGHTED, bool FULL>
+// KEEP: an id with kDroppedBit set is an edge removed by edge dropout — its gather is redirected to
+// row 0 (L1-hot) and its contribution replaced by zeros (a select, not 0 * x: Inf / NaN in a
+// dropped edge's source row must not leak into the sum).
+template <int LPR, bool WEIGHTED, bool FULL, bool KEEP>
 __device__ __forceinline__ void gather_batch(const float* __restrict__ Xc, int64_t ldx,
                                              int my_idx, float my_w, int n, int sub,
                                              float4& acc) {
@@ -46,12 +51,14 @@ __device__ __forceinline__ void gather_batch(const float* __restrict__ Xc, int64
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const int e = (s + u) * EPI + sub;
-      const int idx = __shfl(my_idx, e, kWave);
+      int idx = __shfl(my_idx, e, kWave);
       if (WEIGHTED) w[u] = __shfl(my_w, e, kWave);
+      const bool dropped = KEEP && idx < 0;
+      if (KEEP) idx &= 0x7fffffff;
       // Lanes past the end of a tail batch carry the first id of the batch
       // (a valid row) and are zeroed below, so no load leaves the matrix.
       v[u] = ld4(Xc + (int64_t)idx * ldx);
-      if (!FULL && e >= n) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((!FULL && e >= n) || dropped) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (WEIGHTED) {
 #pragma unroll
@@ -75,10 +82,22 @@ __device__ __forceinline__ void gather_batch(const float* __restrict__ Xc, int64
 
 // Sum of edges [start, end) of one row over this lane's 4 columns; the result
 // is complete (all 64/LPR lane groups combined) in every lane.
-template <int LPR, bool HAS_VALS, bool HAS_SS>
+// id of edge q as the gathers will use it: the source id, or (KEEP) kDroppedBit | 0 when
+// keep(eid[q]) says the edge was dropped.
+template <bool KEEP>
+__device__ __forceinline__ int fetch_id(const int32_t* __restrict__ indices, const int32_t* __restrict__ eid,
+                                        const KeepSeg* __restrict__ keep, int n_keep, int q) {
+  int idx = indices[q];
+  if (KEEP && !edge_kept(keep, n_keep, (uint32_t)eid[q])) idx = (int)kDroppedBit;
+  return idx;
+}
+
+template <int LPR, bool HAS_VALS, bool HAS_SS, bool KEEP>
 __device__ __forceinline__ float4 segment_vec4(const int32_t* __restrict__ indices,
                                                const float* __restrict__ vals,
                                                const float* __restrict__ src_scale,
+                                               const int32_t* __restrict__ eid,
+                                               const KeepSeg* __restrict__ keep, int n_keep,
                                                const float* __restrict__ Xc, int64_t ldx,
                                                int start, int end, int lane) {
   constexpr bool WEIGHTED = HAS_VALS || HAS_SS;
@@ -91,10 +110,10 @@ __device__ __forceinline__ float4 segment_vec4(const int32_t* __restrict__ indic
   if (start < end) {
     const int p = start + lane;
     const int q = p < end ? p : start;
-    nxt_idx = indices[q];
+    nxt_idx = fetch_id<KEEP>(indices, eid, keep, n_keep, q);
     if (WEIGHTED) {
       float w = HAS_VALS ? vals[q] : 1.f;
-      if (HAS_SS) w *= src_scale[nxt_idx];
+      if (HAS_SS) w *= src_scale[KEEP ? nxt_idx & 0x7fffffff : nxt_idx];
       nxt_w = w;
     }
   }
@@ -106,17 +125,17 @@ __device__ __forceinline__ float4 segment_vec4(const int32_t* __restrict__ indic
     if (nb < end) {
       const int p = nb + lane;
       const int q = p < end ? p : nb;
-      nxt_idx = indices[q];
+      nxt_idx = fetch_id<KEEP>(indices, eid, keep, n_keep, q);
       if (WEIGHTED) {
         float w = HAS_VALS ? vals[q] : 1.f;
-        if (HAS_SS) w *= src_scale[nxt_idx];
+        if (HAS_SS) w *= src_scale[KEEP ? nxt_idx & 0x7fffffff : nxt_idx];
         nxt_w = w;
       }
     }
     if (n >= kWave)
-      gather_batch<LPR, WEIGHTED, true>(Xc, ldx, my_idx, my_w, kWave, sub, acc);
+      gather_batch<LPR, WEIGHTED, true, KEEP>(Xc, ldx, my_idx, my_w, kWave, sub, acc);
     else
-      gather_batch<LPR, WEIGHTED, false>(Xc, ldx, my_idx, my_w, n, sub, acc);
+      gather_batch<LPR, WEIGHTED, false, KEEP>(Xc, ldx, my_idx, my_w, n, sub, acc);
   }
   // combine the 64/LPR partial rows (fixed order -> deterministic)
 #pragma unroll
@@ -130,10 +149,12 @@ __device__ __forceinline__ float4 segment_vec4(const int32_t* __restrict__ indic
 }
 
 // Same for one column per lane (any F, any alignment).
-template <bool HAS_VALS, bool HAS_SS>
+template <bool HAS_VALS, bool HAS_SS, bool KEEP>
 __device__ __forceinline__ float segment_dword(const int32_t* __restrict__ indices,
                                                const float* __restrict__ vals,
                                                const float* __restrict__ src_scale,
+                                               const int32_t* __restrict__ eid,
+                                               const KeepSeg* __restrict__ keep, int n_keep,
                                                const float* __restrict__ Xc, int64_t ldx,
                                                int start, int end, int lane) {
   constexpr bool WEIGHTED = HAS_VALS || HAS_SS;
@@ -141,11 +162,11 @@ __device__ __forceinline__ float segment_dword(const int32_t* __restrict__ indic
   for (int base = start; base < end; base += kWave) {
     const int n = min(kWave, end - base);
     const int q = lane < n ? base + lane : base;
-    const int my_idx = indices[q];
+    const int my_idx = fetch_id<KEEP>(indices, eid, keep, n_keep, q);
     float my_w = 0.f;
     if (WEIGHTED) {
       my_w = HAS_VALS ? vals[q] : 1.f;
-      if (HAS_SS) my_w *= src_scale[my_idx];
+      if (HAS_SS) my_w *= src_scale[KEEP ? my_idx & 0x7fffffff : my_idx];
     }
 #pragma unroll 1
     for (int s = 0; s < n; s += kUnroll) {
@@ -153,10 +174,12 @@ __device__ __forceinline__ float segment_dword(const int32_t* __restrict__ indic
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         const int e = s + u;  // < 64 because n <= 64 and 64 % kUnroll == 0
-        const int idx = __shfl(my_idx, e, kWave);
+        int idx = __shfl(my_idx, e, kWave);
         if (WEIGHTED) w[u] = __shfl(my_w, e, kWave);
+        const bool dropped = KEEP && idx < 0;
+        if (KEEP) idx &= 0x7fffffff;
         v[u] = Xc[(int64_t)idx * ldx];
-        if (e >= n) v[u] = 0.f;
+        if (e >= n || dropped) v[u] = 0.f;
       }
       if (WEIGHTED) {
 #pragma unroll

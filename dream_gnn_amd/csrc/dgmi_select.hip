@@ -1,16 +1,20 @@
-// dgmi_select.hip — exact-size uniformly random edge subset as a 0/1 mask (gfx950).
+// dgmi_select.hip — exact-size uniformly random edge subset (gfx950): selection + mask.
 //
 // The reference drops edges every training iteration by keeping the first
 // max(1, int(E*(1-p))) entries of torch.randperm(E) (augmentation.py:48-52, 114-118): a
 // uniformly random subset of exactly that size.  A full random permutation is a sort of E keys;
 // only the subset is needed.  Here every edge e gets the key (hash32(seed, e), e) — unique by
 // construction — and the keep-th smallest key is found by a 4-pass most-significant-byte radix
-// SELECT (256-bin histogram of the candidates per pass, no data movement), then one pass writes
-// mask[e] = key(e) <= threshold.  Pure integer work, nothing is read but the 4 KiB state; the
-// result is a deterministic function of (seed, E, keep), restated bit for bit by the oracle.
+// SELECT (256-bin histogram of the candidates per pass, no data movement) plus one pass that
+// lists the edges whose hash equals the threshold (ties, ordered by id).  The result is the 8-word
+// description of dgmi_keep.h (seed, threshold hash, tie cut): the SpMM kernels evaluate it per edge
+// while they walk their own layout; a 0/1 mask over the COO order is one more pass, on demand.
+// Pure integer work, nothing is read but the 4 KiB state; deterministic in (seed, E, keep),
+// restated bit for bit by the oracle.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dgmi_keep.h"
 #include "dgmi_kernels.h"
 
 namespace dgmi {
@@ -27,14 +31,6 @@ struct SelectState {
   uint32_t n_ties;
   uint32_t ties[kTieCap];
 };
-
-__device__ __forceinline__ uint32_t edge_hash(uint64_t seed, uint64_t e) {
-  uint64_t z = seed + (e + 1) * 0x9E3779B97F4A7C15ull;  // splitmix64 finaliser
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
-}
 
 __global__ void init_state_kernel(SelectState* st, int64_t keep) {
   const int t = threadIdx.x;
@@ -76,44 +72,59 @@ __global__ void pick_kernel(SelectState* st, int shift) {
   for (int i = 0; i < 256; ++i) st->hist[i] = 0;
 }
 
-__global__ __launch_bounds__(kBlock) void mask_kernel(int64_t E, uint64_t seed, SelectState* st,
-                                                      float* __restrict__ mask) {
+// lists the edges whose hash equals the threshold (~E / 2^32 of them)
+__global__ __launch_bounds__(kBlock) void ties_collect_kernel(int64_t E, uint64_t seed, SelectState* st) {
   const uint32_t thr = st->prefix;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += stride) {
-    const uint32_t h = edge_hash(seed, (uint64_t)e);
-    mask[e] = h < thr ? 1.f : 0.f;
-    if (h == thr) {  // ~E / 2^32 edges: decided by edge id in ties_kernel
+    if (edge_hash(seed, (uint64_t)e) == thr) {
       const uint32_t slot = atomicAdd(&st->n_ties, 1u);
       if (slot < (uint32_t)kTieCap) st->ties[slot] = (uint32_t)e;
     }
   }
 }
 
-// one thread: among the edges whose hash equals the threshold keep the `remaining` smallest ids
-__global__ void ties_kernel(int64_t E, uint64_t seed, SelectState* st, float* __restrict__ mask) {
+// one thread: among the ties keep the `remaining` smallest ids -> tie_cut; write the description
+__global__ void finalize_kernel(int64_t E, uint64_t seed, uint32_t e_offset, SelectState* st, KeepSeg* out) {
   if (threadIdx.x != 0) return;
+  const uint32_t thr = st->prefix;
+  int32_t tie_cut = -1;
   if (st->n_ties > (uint32_t)kTieCap) {
     // More ties than the list holds (expected count is E / 2^32 < 1, so this is a degenerate
     // hash / seed): stay exact with a sequential scan in edge-id order instead of mis-counting.
-    const uint32_t thr = st->prefix;
     int64_t left = st->remaining;
     for (int64_t e = 0; e < E && left > 0; ++e)
       if (edge_hash(seed, (uint64_t)e) == thr) {
-        mask[e] = 1.f;
+        tie_cut = (int32_t)e;
         --left;
       }
-    return;
+  } else {
+    const uint32_t n = st->n_ties;
+    for (uint32_t i = 1; i < n; ++i) {  // insertion sort by edge id
+      const uint32_t v = st->ties[i];
+      uint32_t j = i;
+      for (; j > 0 && st->ties[j - 1] > v; --j) st->ties[j] = st->ties[j - 1];
+      st->ties[j] = v;
+    }
+    const int64_t take = st->remaining < (int64_t)n ? st->remaining : (int64_t)n;
+    if (take > 0) tie_cut = (int32_t)st->ties[take - 1];
   }
-  const uint32_t n = st->n_ties;
-  for (uint32_t i = 1; i < n; ++i) {  // insertion sort by edge id
-    const uint32_t v = st->ties[i];
-    uint32_t j = i;
-    for (; j > 0 && st->ties[j - 1] > v; --j) st->ties[j] = st->ties[j - 1];
-    st->ties[j] = v;
-  }
-  const int64_t take = st->remaining < (int64_t)n ? st->remaining : (int64_t)n;
-  for (int64_t i = 0; i < take; ++i) mask[st->ties[i]] = 1.f;
+  KeepSeg sg;
+  sg.e_begin = e_offset;
+  sg.e_end = e_offset + (uint32_t)E;
+  sg.seed_lo = (uint32_t)seed;
+  sg.seed_hi = (uint32_t)(seed >> 32);
+  sg.thr = thr;
+  sg.tie_cut = tie_cut;
+  sg.reserved0 = sg.reserved1 = 0;
+  *out = sg;
+}
+
+__global__ __launch_bounds__(kBlock) void keep_mask_kernel(const KeepSeg* __restrict__ tab, int n_seg, int64_t E,
+                                                           float* __restrict__ mask) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += stride)
+    mask[e] = edge_kept(tab, n_seg, (uint32_t)e) ? 1.f : 0.f;
 }
 
 inline unsigned grid_for(int64_t n) {
@@ -125,20 +136,35 @@ inline unsigned grid_for(int64_t n) {
 
 }  // namespace
 
-size_t random_subset_workspace_bytes() { return sizeof(SelectState); }
+size_t random_subset_workspace_bytes() { return sizeof(SelectState) + sizeof(KeepSeg); }
 
-hipError_t random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask, void* workspace,
-                                  hipStream_t s) {
-  if (E == 0) return hipSuccess;
+hipError_t random_subset_select(int64_t E, int64_t keep, uint64_t seed, uint32_t e_offset, void* seg_out,
+                                void* workspace, hipStream_t s) {
   SelectState* st = static_cast<SelectState*>(workspace);
   hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(256), 0, s, st, keep);
   for (int shift = 24; shift >= 0; shift -= 8) {
     hipLaunchKernelGGL(hist_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, E, seed, st, shift);
     hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(64), 0, s, st, shift);
   }
-  hipLaunchKernelGGL(mask_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, E, seed, st, mask);
-  hipLaunchKernelGGL(ties_kernel, dim3(1), dim3(64), 0, s, E, seed, st, mask);
+  hipLaunchKernelGGL(ties_collect_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, E, seed, st);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, s, E, seed, e_offset, st, static_cast<KeepSeg*>(seg_out));
   return hipGetLastError();
+}
+
+hipError_t keep_mask_f32(const void* table, int n_seg, int64_t E, float* mask, hipStream_t s) {
+  if (E == 0) return hipSuccess;
+  hipLaunchKernelGGL(keep_mask_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, static_cast<const KeepSeg*>(table), n_seg,
+                     E, mask);
+  return hipGetLastError();
+}
+
+hipError_t random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask, void* workspace,
+                                  hipStream_t s) {
+  if (E == 0) return hipSuccess;
+  KeepSeg* seg = reinterpret_cast<KeepSeg*>(static_cast<char*>(workspace) + sizeof(SelectState));
+  hipError_t err = random_subset_select(E, keep, seed, 0u, seg, workspace, s);
+  if (err != hipSuccess) return err;
+  return keep_mask_f32(seg, 1, E, mask, s);
 }
 
 }  // namespace dgmi

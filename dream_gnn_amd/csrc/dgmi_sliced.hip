@@ -42,12 +42,15 @@ __device__ __forceinline__ void store_plane_row(float* p, const float4& v) {
 //
 // grid.x = n_slices * ceil(rows / (4 waves * G groups * kRowsPerGroup)); block b: slice = b % n_slices.
 // Rows [row_begin, row_end) of every slice; plane row index is relative to row_begin.
-template <int LPR, bool HAS_VALS, bool HAS_SS>
+// KEEP: edge dropout on the fly — an edge whose keep(eid[p]) fails (dgmi_keep.h) is flagged in the sign
+// bit of its source id; its gather goes to row 0 (L1-hot) and its contribution is replaced by zeros.
+template <int LPR, bool HAS_VALS, bool HAS_SS, bool KEEP>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ indices,
     const float* __restrict__ vals, const float* __restrict__ X, int64_t ldx,
     const float* __restrict__ src_scale, float* __restrict__ planes, int64_t ldp, int64_t n_dst,
-    int64_t row_begin, int64_t row_end, int F, int n_slices) {
+    int64_t row_begin, int64_t row_end, int F, int n_slices, const int32_t* __restrict__ eid,
+    const KeepSeg* __restrict__ keep, int n_keep) {
   constexpr int G = kWave / LPR;
   constexpr int R = kRowsPerGroup < LPR ? kRowsPerGroup : LPR - 1;
   constexpr bool WEIGHTED = HAS_VALS || HAS_SS;
@@ -77,10 +80,10 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
   float nxt_w = 0.f;
   if (e_begin < e_end) {
     const int q = e_begin + glane < e_end ? e_begin + glane : e_begin;
-    nxt_idx = indices[q];
+    nxt_idx = fetch_id<KEEP>(indices, eid, keep, n_keep, q);
     if (WEIGHTED) {
       nxt_w = HAS_VALS ? vals[q] : 1.f;
-      if (HAS_SS) nxt_w *= src_scale[nxt_idx];
+      if (HAS_SS) nxt_w *= src_scale[KEEP ? nxt_idx & 0x7fffffff : nxt_idx];
     }
   }
   for (int base = e_begin; base < e_end; base += LPR) {
@@ -90,10 +93,10 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
     if (base + LPR < e_end) {
       const int nb = base + LPR;
       const int q = nb + glane < e_end ? nb + glane : nb;
-      nxt_idx = indices[q];
+      nxt_idx = fetch_id<KEEP>(indices, eid, keep, n_keep, q);
       if (WEIGHTED) {
         nxt_w = HAS_VALS ? vals[q] : 1.f;
-        if (HAS_SS) nxt_w *= src_scale[nxt_idx];
+        if (HAS_SS) nxt_w *= src_scale[KEEP ? nxt_idx & 0x7fffffff : nxt_idx];
       }
     }
     for (int j = 0; j < n; j += kUnroll) {
@@ -102,9 +105,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         const int e = j + u;  // < LPR
-        const int idx = __shfl(my_idx, gbase + e, kWave);
+        int idx = __shfl(my_idx, gbase + e, kWave);
         if (WEIGHTED) w[u] = __shfl(my_w, gbase + e, kWave);
+        const bool dropped = KEEP && idx < 0;
+        if (KEEP) idx &= 0x7fffffff;
         v[u] = ld4(Xc + (int64_t)idx * ldx);
+        if (dropped) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       // fast path (group-uniform): all 8 edges belong to the current row -> balanced tree, no
       // per-edge boundary tests
@@ -222,16 +228,20 @@ hipError_t launch_sliced(const SlicedArgs& a, int64_t row_begin, int64_t row_end
   const int64_t blocks = (row_end - row_begin + per_block - 1) / per_block;
   dim3 grid((unsigned)(blocks * a.n_slices), (unsigned)((a.F + 4 * LPR - 1) / (4 * LPR)));
   dim3 block(kWave * kWavesPerBlock);
-  const int key = (a.vals ? 2 : 0) | (a.src_scale ? 1 : 0);
-#define DGMI_LAUNCH(V, S)                                                                        \
-  hipLaunchKernelGGL((spmm_sliced_vec4_kernel<LPR, V, S>), grid, block, 0, s, a.segptr, a.indices, \
-                     a.vals, a.X, a.ldx, a.src_scale, a.planes, a.ldp, a.n_dst, row_begin, row_end, \
-                     (int)a.F, (int)a.n_slices)
+  const int key = (a.vals ? 4 : 0) | (a.src_scale ? 2 : 0) | (a.n_keep > 0 ? 1 : 0);
+#define DGMI_LAUNCH(V, S, K)                                                                          \
+  hipLaunchKernelGGL((spmm_sliced_vec4_kernel<LPR, V, S, K>), grid, block, 0, s, a.segptr, a.indices,  \
+                     a.vals, a.X, a.ldx, a.src_scale, a.planes, a.ldp, a.n_dst, row_begin, row_end,     \
+                     (int)a.F, (int)a.n_slices, a.eid, static_cast<const KeepSeg*>(a.keep), a.n_keep)
   switch (key) {
-    case 0: DGMI_LAUNCH(false, false); break;
-    case 1: DGMI_LAUNCH(false, true); break;
-    case 2: DGMI_LAUNCH(true, false); break;
-    default: DGMI_LAUNCH(true, true); break;
+    case 0: DGMI_LAUNCH(false, false, false); break;
+    case 1: DGMI_LAUNCH(false, false, true); break;
+    case 2: DGMI_LAUNCH(false, true, false); break;
+    case 3: DGMI_LAUNCH(false, true, true); break;
+    case 4: DGMI_LAUNCH(true, false, false); break;
+    case 5: DGMI_LAUNCH(true, false, true); break;
+    case 6: DGMI_LAUNCH(true, true, false); break;
+    default: DGMI_LAUNCH(true, true, true); break;
   }
 #undef DGMI_LAUNCH
   return hipGetLastError();

@@ -68,26 +68,27 @@ __device__ __forceinline__ bool fetch_segment(const int32_t* __restrict__ indptr
 }
 
 // grid.x = ceil(#segments / 4), grid.y = ceil(F / (4*LPR)); block = 256 (4 waves).
-template <int LPR, bool HAS_VALS, bool HAS_SS, bool HAS_DS, bool PLANNED>
+template <int LPR, bool HAS_VALS, bool HAS_SS, bool KEEP, bool PLANNED>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_csr_vec4_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const float* __restrict__ vals, const float* __restrict__ X, int64_t ldx,
     const float* __restrict__ src_scale, const float* __restrict__ dst_scale,
     float* __restrict__ Y, int64_t ldy, int64_t n_dst, int F,
-    const int32_t* __restrict__ plan, float* __restrict__ P, int64_t ldp) {
+    const int32_t* __restrict__ plan, float* __restrict__ P, int64_t ldp,
+    const int32_t* __restrict__ eid, const KeepSeg* __restrict__ keep, int n_keep) {
   Segment sg;
   if (!fetch_segment<PLANNED>(indptr, plan, n_dst, sg)) return;  // wave-uniform
   const int lane = threadIdx.x & (kWave - 1);
   int col = ((int)blockIdx.y * LPR + (lane % LPR)) * 4;
   const bool col_ok = col < F;
   if (!col_ok) col = 0;  // keep the loads in bounds; result discarded
-  float4 acc = segment_vec4<LPR, HAS_VALS, HAS_SS>(indices, vals, src_scale, X + col, ldx,
-                                                   sg.start, sg.end, lane);
+  float4 acc = segment_vec4<LPR, HAS_VALS, HAS_SS, KEEP>(indices, vals, src_scale, eid, keep, n_keep, X + col, ldx,
+                                                         sg.start, sg.end, lane);
   if (lane < LPR && col_ok) {
     if (PLANNED && sg.slot >= 0) {
       *reinterpret_cast<float4*>(P + (int64_t)sg.slot * ldp + col) = acc;
     } else {
-      if (HAS_DS) {
+      if (dst_scale != nullptr) {
         const float d = dst_scale[sg.row];
         acc.x *= d;
         acc.y *= d;
@@ -101,26 +102,27 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_csr_vec4_kernel(
 
 // Any F, any alignment: lanes across 64 consecutive columns, one dword each;
 // grid.y = ceil(F/64).
-template <bool HAS_VALS, bool HAS_SS, bool HAS_DS, bool PLANNED>
+template <bool HAS_VALS, bool HAS_SS, bool KEEP, bool PLANNED>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_csr_dword_kernel(
     const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
     const float* __restrict__ vals, const float* __restrict__ X, int64_t ldx,
     const float* __restrict__ src_scale, const float* __restrict__ dst_scale,
     float* __restrict__ Y, int64_t ldy, int64_t n_dst, int F,
-    const int32_t* __restrict__ plan, float* __restrict__ P, int64_t ldp) {
+    const int32_t* __restrict__ plan, float* __restrict__ P, int64_t ldp,
+    const int32_t* __restrict__ eid, const KeepSeg* __restrict__ keep, int n_keep) {
   Segment sg;
   if (!fetch_segment<PLANNED>(indptr, plan, n_dst, sg)) return;
   const int lane = threadIdx.x & (kWave - 1);
   int col = (int)blockIdx.y * kWave + lane;
   const bool col_ok = col < F;
   if (!col_ok) col = 0;
-  float acc = segment_dword<HAS_VALS, HAS_SS>(indices, vals, src_scale, X + col, ldx,
-                                              sg.start, sg.end, lane);
+  float acc = segment_dword<HAS_VALS, HAS_SS, KEEP>(indices, vals, src_scale, eid, keep, n_keep, X + col, ldx,
+                                                    sg.start, sg.end, lane);
   if (col_ok) {
     if (PLANNED && sg.slot >= 0) {
       P[(int64_t)sg.slot * ldp + col] = acc;
     } else {
-      if (HAS_DS) acc *= dst_scale[sg.row];
+      if (dst_scale != nullptr) acc *= dst_scale[sg.row];
       Y[sg.row * ldy + col] = acc;
     }
   }
@@ -174,11 +176,12 @@ template <int LPR, bool PLANNED>
 hipError_t launch_vec4(const SpmmArgs& a, int64_t segments, hipStream_t s) {
   dim3 grid(blocks_for(segments), (unsigned)((a.F + 4 * LPR - 1) / (4 * LPR)));
   dim3 block(kWave * kWavesPerBlock);
-  const int key = (a.vals ? 4 : 0) | (a.src_scale ? 2 : 0) | (a.dst_scale ? 1 : 0);
-#define DGMI_LAUNCH(V, S, D)                                                              \
-  hipLaunchKernelGGL((spmm_csr_vec4_kernel<LPR, V, S, D, PLANNED>), grid, block, 0, s,     \
+  const int key = (a.vals ? 4 : 0) | (a.src_scale ? 2 : 0) | (a.n_keep > 0 ? 1 : 0);
+#define DGMI_LAUNCH(V, S, K)                                                              \
+  hipLaunchKernelGGL((spmm_csr_vec4_kernel<LPR, V, S, K, PLANNED>), grid, block, 0, s,     \
                      a.indptr, a.indices, a.vals, a.X, a.ldx, a.src_scale, a.dst_scale,    \
-                     a.Y, a.ldy, a.n_dst, (int)a.F, a.plan, a.partials, a.ldp)
+                     a.Y, a.ldy, a.n_dst, (int)a.F, a.plan, a.partials, a.ldp, a.eid,      \
+                     static_cast<const KeepSeg*>(a.keep), a.n_keep)
   switch (key) {
     case 0: DGMI_LAUNCH(false, false, false); break;
     case 1: DGMI_LAUNCH(false, false, true); break;
@@ -197,11 +200,12 @@ template <bool PLANNED>
 hipError_t launch_dword(const SpmmArgs& a, int64_t segments, hipStream_t s) {
   dim3 grid(blocks_for(segments), (unsigned)((a.F + kWave - 1) / kWave));
   dim3 block(kWave * kWavesPerBlock);
-  const int key = (a.vals ? 4 : 0) | (a.src_scale ? 2 : 0) | (a.dst_scale ? 1 : 0);
-#define DGMI_LAUNCH(V, S, D)                                                              \
-  hipLaunchKernelGGL((spmm_csr_dword_kernel<V, S, D, PLANNED>), grid, block, 0, s,         \
+  const int key = (a.vals ? 4 : 0) | (a.src_scale ? 2 : 0) | (a.n_keep > 0 ? 1 : 0);
+#define DGMI_LAUNCH(V, S, K)                                                              \
+  hipLaunchKernelGGL((spmm_csr_dword_kernel<V, S, K, PLANNED>), grid, block, 0, s,         \
                      a.indptr, a.indices, a.vals, a.X, a.ldx, a.src_scale, a.dst_scale,    \
-                     a.Y, a.ldy, a.n_dst, (int)a.F, a.plan, a.partials, a.ldp)
+                     a.Y, a.ldy, a.n_dst, (int)a.F, a.plan, a.partials, a.ldp, a.eid,      \
+                     static_cast<const KeepSeg*>(a.keep), a.n_keep)
   switch (key) {
     case 0: DGMI_LAUNCH(false, false, false); break;
     case 1: DGMI_LAUNCH(false, false, true); break;

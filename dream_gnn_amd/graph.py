@@ -100,20 +100,24 @@ class DroppedRelation(RelationGraph):
     """A relation after edge dropout (augmentation.py:13-89), kept as *parent relation + which
     edges survive* instead of a re-sorted copy.
 
-    ``csr`` is a value view of the parent's CSR with a 0/1 keep mask as edge values: no sort, no
-    plan rebuild, no host sync — the per-iteration graph churn of train.py:267 becomes one subset
-    selection and a few gathers.  The kept edge list (``src`` / ``dst``) is materialised only if
-    somebody asks for it (in permutation order when the subset came from ``randperm``, as the
-    reference builds it; in ascending order otherwise).  Dropped edges contribute ``0 * x`` to the
-    sums (identical to removing them for finite x).
+    ``csr`` is a view of the parent's CSR: no sort, no plan rebuild, no host sync — the
+    per-iteration graph churn of train.py:267 becomes one subset selection.  With the default
+    ``"select"`` selection the subset is an 8-word description (``ops.random_subset_select``) that
+    the kernels evaluate per edge while they walk the parent's layouts (``CSRGraph.dropped``):
+    nothing of size E is written, dropped edges are skipped.  With ``"randperm"`` (the reference's
+    literal procedure) it is a 0/1 value mask over the parent CSR (dropped edges contribute
+    ``0 * x``).  The kept edge list (``src`` / ``dst``) is materialised only if somebody asks for
+    it (in permutation order when the subset came from ``randperm``, as the reference builds it;
+    in ascending order otherwise).
     """
 
     def __init__(self, parent: RelationGraph, n_keep: int, srcdata: dict, dstdata: dict,
-                 keep_idx: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None):
+                 keep_idx: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                 desc: Optional[torch.Tensor] = None):
         self.canonical = parent.canonical
         self.parent = parent
         self.n_keep = int(n_keep)
-        self._keep_idx, self._mask = keep_idx, mask
+        self._keep_idx, self._mask, self.desc = keep_idx, mask, desc
         self.n_src, self.n_dst = parent.n_src, parent.n_dst
         self.srcdata, self.dstdata = srcdata, dstdata
         self._csr = None
@@ -126,14 +130,17 @@ class DroppedRelation(RelationGraph):
     def keep_idx(self) -> torch.Tensor:
         """Positions of the kept edges in the parent's edge list."""
         if self._keep_idx is None:
-            self._keep_idx = torch.nonzero(self._mask, as_tuple=True)[0]  # host sync: only on demand
+            self._keep_idx = torch.nonzero(self.keep_mask(), as_tuple=True)[0]  # host sync: only on demand
         return self._keep_idx
 
     def keep_mask(self) -> torch.Tensor:
-        """float 0/1 over the parent's edges."""
+        """float 0/1 over the parent's edges (materialised on demand)."""
         if self._mask is None:
-            m = torch.zeros(self.parent.number_of_edges(), dtype=torch.float32, device=self._keep_idx.device)
-            self._mask = m.index_fill_(0, self._keep_idx, 1.0)  # (m[idx] = 1.0 would synchronise with the host)
+            if self.desc is not None:
+                self._mask = ops.keep_mask(self.desc, self.parent.number_of_edges())
+            else:
+                m = torch.zeros(self.parent.number_of_edges(), dtype=torch.float32, device=self._keep_idx.device)
+                self._mask = m.index_fill_(0, self._keep_idx, 1.0)  # (m[idx] = 1.0 would synchronise with the host)
         return self._mask
 
     def _materialise(self):
@@ -159,7 +166,8 @@ class DroppedRelation(RelationGraph):
     @property
     def csr(self) -> ops.CSRGraph:
         if self._csr is None:
-            self._csr = self.parent.csr.masked(self.keep_mask())
+            base = self.parent.csr
+            self._csr = base.dropped(self.desc) if self.desc is not None else base.masked(self.keep_mask())
         return self._csr
 
 
@@ -309,8 +317,23 @@ class HeteroGraph:
         if parent is not None and all(isinstance(self._rels[c], DroppedRelation) for c in cans):
             base = parent.fused_relations(dst_type)  # built (and validated) once on the parent
             if base is not None and base[1] == cans:
-                mask = torch.cat([self._rels[c].keep_mask() for c in cans])
-                cache[dst_type] = (base[0].masked(mask), cans)
+                rels = [self._rels[c] for c in cans]
+                if all(r.desc is not None for r in rels) and len(rels) <= 8:
+                    # relation i's edges sit at [off_i, off_i + E_i) of the fused edge order: shift the
+                    # e_begin / e_end words of its description (offset vectors are cached on the parent)
+                    offs = parent.__dict__.setdefault("_fused_offsets", {}).get(dst_type)
+                    if offs is None:
+                        starts, acc = [], 0
+                        for c in cans:
+                            starts.append(acc)
+                            acc += parent._rels[c].number_of_edges()
+                        offs = torch.zeros((len(cans), 8), dtype=torch.int32)
+                        offs[:, 0] = offs[:, 1] = torch.tensor(starts, dtype=torch.int32)
+                        offs = parent.__dict__["_fused_offsets"][dst_type] = offs.to(rels[0].desc.device)
+                    view = base[0].dropped(torch.stack([r.desc for r in rels]) + offs)
+                else:
+                    view = base[0].masked(torch.cat([r.keep_mask() for r in rels]))
+                cache[dst_type] = (view, cans)
                 return cache[dst_type]
         if cans and len({c[0] for c in cans}) == 1 and len({self._rels[c].src.device for c in cans}) == 1:
             R = len(cans)
@@ -425,17 +448,21 @@ def _draw_seed(generator: Optional[torch.Generator]) -> Optional[int]:
 
 
 def _select_kept(E: int, keep: int, device, generator, selection: Optional[str]):
-    """(keep_idx or None, mask or None) for a uniformly random subset of exactly ``keep`` edges.
+    """(keep_idx or None, desc or None) for a uniformly random subset of exactly ``keep`` edges.
 
-    ``"select"`` (default on the GPU): ``dgmi_random_subset_mask_f32`` — radix select on per-edge
-    hash keys, no permutation is materialised.  ``"randperm"``: the reference's literal procedure,
-    ``torch.randperm(E)[:keep]`` (augmentation.py:51-52)."""
+    ``"select"`` (default on the GPU): ``dgmi_random_subset_select`` — radix select on per-edge
+    hash keys; the result is the subset's 8-word description, no permutation and no mask is
+    materialised.  It consumes ONE ``randint`` draw of the torch CPU generator (the seed), where the
+    reference consumes a ``randperm(E)`` — the torch RNG stream after augmentation therefore differs
+    from the reference's (a documented deviation; the subset is uniformly random either way).
+    ``"randperm"``: the reference's literal procedure, ``torch.randperm(E)[:keep]``
+    (augmentation.py:51-52), same RNG consumption as the reference."""
     if selection is None:
         selection = "select" if torch.device(device).type == "cuda" else "randperm"
     if selection == "select":
         seed = _draw_seed(generator)
         if seed is not None:
-            return None, ops.random_subset_mask(E, keep, seed, device)
+            return None, ops.random_subset_select(E, keep, seed, device)
     return torch.randperm(E, device=device, generator=generator)[:keep], None
 
 
@@ -470,8 +497,8 @@ def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
             out._rels[can] = child
             continue
         keep = max(1, int(E * (1 - dropout_rate)))
-        keep_idx, mask = _select_kept(E, keep, rel.device, generator, selection)
-        out._rels[can] = DroppedRelation(rel, keep, out._ndata[st], out._ndata[dt], keep_idx=keep_idx, mask=mask)
+        keep_idx, desc = _select_kept(E, keep, rel.device, generator, selection)
+        out._rels[can] = DroppedRelation(rel, keep, out._ndata[st], out._ndata[dt], keep_idx=keep_idx, desc=desc)
     if not nested:
         out.__dict__["_dropout_parent"] = graph
     for nt in graph.ntypes:
@@ -496,10 +523,10 @@ def random_edge_dropout_sparse(adj, dropout_rate: float = 0.1, generator: Option
         base = adjacency_csr(adj)
         E = base.nnz
         keep = max(1, int(E * (1 - dropout_rate)))
-        keep_idx, mask = _select_kept(E, keep, base.device, generator, selection)
-        if mask is None:
-            mask = torch.zeros(E, dtype=torch.float32, device=base.device).index_fill_(0, keep_idx, 1.0)
-        return base.masked(mask)
+        keep_idx, desc = _select_kept(E, keep, base.device, generator, selection)
+        if desc is not None:
+            return base.dropped(desc)
+        return base.masked(torch.zeros(E, dtype=torch.float32, device=base.device).index_fill_(0, keep_idx, 1.0))
     idx, val = adj._indices(), adj._values()
     E = val.shape[0]
     keep = max(1, int(E * (1 - dropout_rate)))

@@ -63,6 +63,20 @@ def _check(t, dtype, name, ndim=None):
         raise RuntimeError("%s must be contiguous" % name)
 
 
+_SCRATCH = {}
+
+
+def _scratch(nbytes: int, dev, tag: str) -> torch.Tensor:
+    """Kernel scratch (chunk partials, partial planes): ONE buffer per (device, stream, kind), grown
+    on demand and reused by every product issued on that stream — products on a stream are ordered,
+    so they can share it, and nothing is allocated per call.  Contents are never read across calls."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tag)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _SCRATCH[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    return buf
+
+
 def csr_from_coo(row: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: int = 0,
                  check_range: bool = False, return_flag: bool = False):
     """Stable COO -> CSR on the device: ``(indptr[n_rows+1], indices[E], eid[E])``, all int32.
@@ -142,6 +156,7 @@ class SpmmPlan:
             b = self._pbytes[F] = int(_L.dgmi_spmm_partials_bytes(self.nnz, self.chunk, int(F)))
         return b
 
+
     def header(self):
         """(n_items, n_long_rows, n_slots, chunk, ...) — reads the device header back (tests)."""
         return tuple(int(v) for v in self.buf[:64].view(torch.int32).tolist())
@@ -151,21 +166,31 @@ def build_plan(indptr: torch.Tensor, nnz: int, chunk: Optional[int] = None) -> S
     return SpmmPlan(indptr, nnz, chunk)
 
 
-def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx):
-    """Validated arguments -> one C-ABI call on torch's current stream."""
+def _keep_args(eid, keep):
+    """(eid pointer, table pointer, n descriptions) of an on-the-fly edge dropout, or three nulls."""
+    if keep is None:
+        return None, None, 0
+    return eid.data_ptr(), keep.data_ptr(), int(keep.shape[0])
+
+
+def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx,
+                 eid=None, keep=None):
+    """Validated arguments -> one C-ABI call on torch's current stream.  ``keep``: (n, 8) int32
+    subset descriptions (``random_subset_select``) applied through ``eid`` on the fly."""
+    p_eid, p_keep, n_keep = _keep_args(eid, keep)
     with _guard(dev):
         if plan is None:
-            rc = _L.dgmi_spmm_csr_f32(indptr.data_ptr(), indices.data_ptr(), _ptr(vals), X.data_ptr(), ldx,
-                                      _ptr(src_scale), _ptr(dst_scale), out.data_ptr(), max(F, 1), n_dst, n_src, F,
-                                      _stream(dev))
+            rc = _L.dgmi_spmm_csr_f32(indptr.data_ptr(), indices.data_ptr(), _ptr(vals), p_eid, p_keep, n_keep,
+                                      X.data_ptr(), ldx, _ptr(src_scale), _ptr(dst_scale), out.data_ptr(), max(F, 1),
+                                      n_dst, n_src, F, _stream(dev))
             if rc:
                 _lib.check(rc, "dgmi_spmm_csr_f32")
         else:
             pbytes = plan.partials_bytes(F)
-            partials = torch.empty(pbytes, dtype=torch.uint8, device=dev)  # caching allocator: stream-safe scratch
-            rc = _L.dgmi_spmm_csr_planned_f32(indptr.data_ptr(), indices.data_ptr(), _ptr(vals), X.data_ptr(), ldx,
-                                              _ptr(src_scale), _ptr(dst_scale), out.data_ptr(), max(F, 1), n_dst,
-                                              n_src, F, plan.nnz, plan.chunk, plan.buf.data_ptr(),
+            partials = _scratch(pbytes, dev, "partials")
+            rc = _L.dgmi_spmm_csr_planned_f32(indptr.data_ptr(), indices.data_ptr(), _ptr(vals), p_eid, p_keep, n_keep,
+                                              X.data_ptr(), ldx, _ptr(src_scale), _ptr(dst_scale), out.data_ptr(),
+                                              max(F, 1), n_dst, n_src, F, plan.nnz, plan.chunk, plan.buf.data_ptr(),
                                               partials.data_ptr(), pbytes, _stream(dev))
             if rc:
                 _lib.check(rc, "dgmi_spmm_csr_planned_f32")
@@ -196,10 +221,15 @@ def _prep_scale(s, n, name):
 
 
 def spmm_csr_raw(indptr, indices, vals, X, src_scale=None, dst_scale=None, out=None,
-                 plan: Optional[SpmmPlan] = None) -> torch.Tensor:
+                 plan: Optional[SpmmPlan] = None, eid=None, keep=None) -> torch.Tensor:
     """One SpMM launch through the C ABI, no autograd.  X may be a row-strided 2-D view.
-    ``plan=None``: ``dgmi_spmm_csr_f32`` (a wave per row); else ``dgmi_spmm_csr_planned_f32``."""
-    dev = _require_device(indptr, indices, vals, X, src_scale, dst_scale, out)
+    ``plan=None``: ``dgmi_spmm_csr_f32`` (a wave per row); else ``dgmi_spmm_csr_planned_f32``.
+    ``keep`` (with ``eid``): subset descriptions for edge dropout on the fly."""
+    dev = _require_device(indptr, indices, vals, X, src_scale, dst_scale, out, eid, keep)
+    if keep is not None:
+        keep = _prep_keep(keep)
+        if eid is None or eid.shape[0] != indices.shape[0]:
+            raise RuntimeError("edge dropout on the fly needs the layout's eid array")
     _check(indptr, torch.int32, "indptr", 1)
     _check(indices, torch.int32, "indices", 1)
     X, n_src, F, ldx = _prep_dense(X)
@@ -218,7 +248,17 @@ def spmm_csr_raw(indptr, indices, vals, X, src_scale=None, dst_scale=None, out=N
             raise RuntimeError("out has shape %s, expected %s" % (tuple(out.shape), (n_dst, F)))
     if plan is not None and (plan.n_rows != n_dst or plan.nnz != indices.shape[0]):
         raise RuntimeError("plan was built for another CSR")
-    return _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx)
+    return _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx, eid, keep)
+
+
+def _prep_keep(keep):
+    """Subset descriptions as an (n, 8) contiguous int32 tensor."""
+    if keep.dtype != torch.int32 or keep.dim() not in (1, 2) or keep.shape[-1] != 8:
+        raise RuntimeError("keep must be int32 with 8 words per description, got %s %s" % (keep.dtype, tuple(keep.shape)))
+    keep = keep.reshape(-1, 8)
+    if keep.shape[0] > 8:
+        raise RuntimeError("at most 8 subset descriptions per product")
+    return keep if keep.is_contiguous() else keep.contiguous()
 
 
 def _sliced_ok(X, out) -> bool:
@@ -254,13 +294,16 @@ class SlicedCSR:
                        "dgmi_csr_sliced_from_coo_i32")
         self.vals = None if vals is None else gather_f32(vals, self.eid)
         self._pbytes = {}
+        self.range_flag = ws[:4].view(torch.int32).clone()  # 1 if an id was out of range (device; not read here)
 
     _DEFAULT = object()
 
-    def spmm(self, X, src_scale=None, dst_scale=None, out=None, vals=_DEFAULT):
-        """``vals`` (in sliced order, see ``eid``) overrides the values given at construction."""
+    def spmm(self, X, src_scale=None, dst_scale=None, out=None, vals=_DEFAULT, keep=None):
+        """``vals`` (in sliced order, see ``eid``) overrides the values given at construction;
+        ``keep``: subset descriptions applied through ``eid`` (edge dropout on the fly)."""
         vals = self.vals if vals is SlicedCSR._DEFAULT else vals
         dev = self.segptr.device
+        p_eid, p_keep, n_keep = _keep_args(self.eid, None if keep is None else _prep_keep(keep))
         if not X.is_cuda or X.device != dev:
             _require_device(self.segptr, X)
         X, n_x, F, ldx = _prep_dense(X)
@@ -276,82 +319,12 @@ class SlicedCSR:
             pbytes = self._pbytes.get(F)
             if pbytes is None:
                 pbytes = self._pbytes[F] = int(_L.dgmi_spmm_sliced_planes_bytes(self.n_dst, self.n_slices, F))
-            planes = torch.empty(pbytes, dtype=torch.uint8, device=dev)
+            planes = _scratch(pbytes, dev, "planes")
             _lib.check(_L.dgmi_spmm_sliced_f32(self.segptr.data_ptr(), self.indices.data_ptr(), _ptr(vals),
-                                               X.data_ptr(), ldx, _ptr(src_scale), _ptr(dst_scale), out.data_ptr(),
-                                               F, self.n_dst, self.n_src, F, self.n_slices, planes.data_ptr(), pbytes,
-                                               _stream(dev)), "dgmi_spmm_sliced_f32")
-        return out
-
-
-class OwnedCSR:
-    """Row-owned, slice-swept layout (``dgmi_csr_owned_from_coo_i32`` / ``dgmi_spmm_owned_f32``):
-    every lane group of the launch owns a few destination rows (running sums in LDS) and sweeps
-    the source slices in order; no partial planes, Y written once.  The layout depends on the
-    feature-width class (lanes per row) through its geometry, so it is built for one ``F``."""
-
-    def __init__(self, dst, src, n_dst, n_src, F: int = 128, vals=None, blocks_per_cu: int = 0, n_slices: int = 0,
-                 paced: bool = True):
-        dev = _require_device(dst, src, vals)
-        self.paced = paced
-        self.n_dst, self.n_src, self.F = int(n_dst), int(n_src), int(F)
-        self.geom = _lib.OwnedGeom()
-        rc = _L.dgmi_owned_geometry(self.n_dst, self.n_src, self.F, blocks_per_cu, n_slices, ctypes.byref(self.geom))
-        if rc:
-            raise RuntimeError("shape not eligible for the row-owned kernel (needs F %% 4 == 0, F <= 256, "
-                               "n_src < 2^27): n_dst=%d n_src=%d F=%d" % (self.n_dst, self.n_src, self.F))
-        E = dst.shape[0]
-        with _guard(dev):
-            self.seg_ptr = torch.empty(self.geom.n_groups * self.geom.n_slices + 1, dtype=torch.int32, device=dev)
-            self.words = torch.empty(E, dtype=torch.int32, device=dev)  # src | local_row << 27 (bit pattern)
-            self.eid = torch.empty(E, dtype=torch.int32, device=dev)
-            need = ctypes.c_size_t(0)
-            _lib.check(_L.dgmi_csr_owned_from_coo_i32(_ptr(dst), _ptr(src), E, self.n_dst, self.n_src,
-                                                      ctypes.byref(self.geom), None, None, None, None,
-                                                      ctypes.byref(need), None), "dgmi_csr_owned_from_coo_i32(size query)")
-            ws = torch.empty(max(int(need.value), 256), dtype=torch.uint8, device=dev)
-            have = ctypes.c_size_t(ws.numel())
-            _lib.check(_L.dgmi_csr_owned_from_coo_i32(_ptr(dst), _ptr(src), E, self.n_dst, self.n_src,
-                                                      ctypes.byref(self.geom), _ptr(self.seg_ptr), _ptr(self.words),
-                                                      _ptr(self.eid), _ptr(ws), ctypes.byref(have), _stream(dev)),
-                       "dgmi_csr_owned_from_coo_i32")
-            self._flag = ws[:4].view(torch.int32).clone()
-            # pacing counters: scratch owned by the layout, reused by every product on it (products on
-            # one layout are stream-ordered; the launch zeroes it)
-            self._pbytes = int(_L.dgmi_spmm_owned_progress_bytes(ctypes.byref(self.geom)))
-            self._progress = torch.empty(max(self._pbytes, 16), dtype=torch.uint8, device=dev)
-        self.vals = None if vals is None else gather_f32(vals, self.eid)
-
-    def fits(self, F: int) -> bool:
-        """Whether a product of width F can run on this layout (same lanes-per-row class)."""
-        return F % 4 == 0 and 0 < F <= 4 * self.geom.lanes_per_row
-
-    _DEFAULT = object()
-
-    def spmm(self, X, src_scale=None, dst_scale=None, out=None, vals=_DEFAULT):
-        vals = self.vals if vals is OwnedCSR._DEFAULT else vals
-        dev = self.seg_ptr.device
-        if not X.is_cuda or X.device != dev:
-            _require_device(self.seg_ptr, X)
-        X, n_x, F, ldx = _prep_dense(X)
-        if n_x != self.n_src:
-            raise RuntimeError("X has %d rows, the graph has %d source nodes" % (n_x, self.n_src))
-        if not self.fits(F):
-            raise RuntimeError("layout was built for F=%d (lanes per row %d); got F=%d"
-                               % (self.F, self.geom.lanes_per_row, F))
-        src_scale = _prep_scale(src_scale, self.n_src, "src_scale")
-        dst_scale = _prep_scale(dst_scale, self.n_dst, "dst_scale")
-        if out is None:
-            out = torch.empty((self.n_dst, F), dtype=torch.float32, device=dev)
-        elif out.dtype != torch.float32 or tuple(out.shape) != (self.n_dst, F) or not out.is_contiguous():
-            raise RuntimeError("out must be a contiguous float32 (%d, %d) tensor" % (self.n_dst, F))
-        with _guard(dev):
-            rc = _L.dgmi_spmm_owned_f32(self.seg_ptr.data_ptr(), self.words.data_ptr(), _ptr(vals), X.data_ptr(), ldx,
-                                        _ptr(src_scale), _ptr(dst_scale), out.data_ptr(), F, self.n_dst, self.n_src, F,
-                                        ctypes.byref(self.geom), self._progress.data_ptr() if self.paced else None,
-                                        self._pbytes, _stream(dev))
-            if rc:
-                _lib.check(rc, "dgmi_spmm_owned_f32")
+                                               p_eid, p_keep, n_keep, X.data_ptr(), ldx, _ptr(src_scale),
+                                               _ptr(dst_scale), out.data_ptr(), F, self.n_dst, self.n_src, F,
+                                               self.n_slices, planes.data_ptr(), pbytes, _stream(dev)),
+                       "dgmi_spmm_sliced_f32")
         return out
 
 
@@ -403,8 +376,8 @@ class _SplitSliced:
         self.c_plan = build_plan(self.c_indptr, self.n_virtual)
         self.n_rows = n_rows
 
-    def spmm(self, X, src_scale, dst_scale, out, vals):
-        yv = self.sliced.spmm(X, src_scale, None, None, vals=vals)
+    def spmm(self, X, src_scale, dst_scale, out, vals, keep=None):
+        yv = self.sliced.spmm(X, src_scale, None, None, vals=vals, keep=keep)
         F = yv.shape[1]
         if out is None:
             out = torch.empty((self.n_rows, F), dtype=torch.float32, device=yv.device)
@@ -455,9 +428,10 @@ class CSRGraph:
         S.plan = build_plan(S.indptr, int(S.indices.shape[0])) if planned else None
 
     # -- values -----------------------------------------------------------------------------------
-    def _set_values(self, coo_vals):
+    def _set_values(self, coo_vals, keep=None):
         self._coo_vals = coo_vals
         self._v = {}  # layout name -> values permuted into that layout
+        self._keep = keep  # (n, 8) int32 subset descriptions applied on the fly, or None
 
     def with_values(self, coo_vals: Optional[torch.Tensor]) -> "CSRGraph":
         """A view sharing this graph's structure (and whatever it builds later) with other per-edge
@@ -466,13 +440,33 @@ class CSRGraph:
             raise RuntimeError("expected %d edge values, got %d" % (self.nnz, coo_vals.shape[0]))
         view = object.__new__(CSRGraph)
         view._S = self._S
-        view._set_values(None if coo_vals is None else coo_vals.to(torch.float32).contiguous())
+        view._set_values(None if coo_vals is None else coo_vals.to(torch.float32).contiguous(), self._keep)
         return view
 
     def masked(self, keep: torch.Tensor) -> "CSRGraph":
         """View with edge e weighted by ``keep[e]`` (0/1), times the existing values if any."""
         keep = keep.to(torch.float32)
-        return self.with_values(keep if self._coo_vals is None else self._coo_vals * keep)
+        view = self.with_values(keep if self._coo_vals is None else self._coo_vals * keep)
+        view._keep = self._keep
+        return view
+
+    def dropped(self, desc: torch.Tensor) -> "CSRGraph":
+        """View of the same structure and values with edge dropout applied ON THE FLY: ``desc`` holds
+        the 8-word description(s) of the surviving subset(s) (``random_subset_select``), evaluated
+        per edge inside the kernels through each layout's ``eid`` — no mask is carried into the
+        layouts, nothing is re-sorted, dropped edges are skipped (not multiplied by zero)."""
+        desc = _prep_keep(desc)
+        view = object.__new__(CSRGraph)
+        view._S = self._S
+        view._coo_vals, view._v = self._coo_vals, self._v  # values (and their per-layout copies) are shared
+        view._keep = desc if self._keep is None else torch.cat([self._keep, desc])
+        if view._keep.shape[0] > 8:
+            raise RuntimeError("at most 8 subset descriptions per graph view")
+        return view
+
+    def keep_mask(self) -> Optional[torch.Tensor]:
+        """float 0/1 mask over the COO edge order of the on-the-fly dropout (None if there is none)."""
+        return None if self._keep is None else keep_mask(self._keep, self.nnz)
 
     def _vals_for(self, layout: str, eid: torch.Tensor):
         if self._coo_vals is None:
@@ -557,7 +551,7 @@ class CSRGraph:
         indptr_t, indices_t, eid_t, plan_t = self._t_struct()
         return indptr_t, indices_t, self._vals_for("csr_t", eid_t), plan_t
 
-    def _run(self, indptr, indices, vals, plan, n_rows, n_cols, X, col_scale, row_scale, out):
+    def _run(self, indptr, indices, vals, plan, n_rows, n_cols, X, col_scale, row_scale, out, eid=None):
         dev = indptr.device
         if not X.is_cuda or X.device != dev:
             _require_device(indptr, X)
@@ -570,7 +564,8 @@ class CSRGraph:
             out = torch.empty((n_rows, F), dtype=torch.float32, device=dev)
         elif out.dtype != torch.float32 or tuple(out.shape) != (n_rows, F) or not out.is_contiguous():
             raise RuntimeError("out must be a contiguous float32 (%d, %d) tensor" % (n_rows, F))
-        return _launch_spmm(dev, indptr, indices, vals, X, col_scale, row_scale, out, plan, n_rows, n_cols, F, ldx)
+        return _launch_spmm(dev, indptr, indices, vals, X, col_scale, row_scale, out, plan, n_rows, n_cols, F, ldx,
+                            eid if self._keep is not None else None, self._keep)
 
     def spmm(self, X, src_scale=None, dst_scale=None, out=None):
         """``diag(dst_scale) A diag(src_scale) X`` (no autograd).  Picks the XCD-local sliced
@@ -580,13 +575,13 @@ class CSRGraph:
         if X.dim() == 2 and self._use_sliced(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
             if S.sliced is None:
                 S.sliced = SlicedCSR(S.dst, S.src, S.n_dst, S.n_src)
-            return S.sliced.spmm(X, src_scale, dst_scale, out, vals=self._vals_for("sliced", S.sliced.eid))
+            return S.sliced.spmm(X, src_scale, dst_scale, out, vals=self._vals_for("sliced", S.sliced.eid), keep=self._keep)
         if X.dim() == 2 and self._use_split(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
             if S.split is None:
                 S.split = _SplitSliced(S.indptr, S.eid, S.src, S.n_dst, S.n_src)
             return S.split.spmm(X, _prep_scale(src_scale, S.n_src, "src_scale"), _prep_scale(dst_scale, S.n_dst, "dst_scale"),
-                                out, self._vals_for("split", S.split.sliced.eid))
-        return self._run(S.indptr, S.indices, self.vals, S.plan, S.n_dst, S.n_src, X, src_scale, dst_scale, out)
+                                out, self._vals_for("split", S.split.sliced.eid), keep=self._keep)
+        return self._run(S.indptr, S.indices, self.vals, S.plan, S.n_dst, S.n_src, X, src_scale, dst_scale, out, S.eid)
 
     def spmm_t(self, dY, src_scale=None, dst_scale=None, out=None):
         """``diag(src_scale) A^T diag(dst_scale) dY`` — the backward of :meth:`spmm`."""
@@ -598,14 +593,15 @@ class CSRGraph:
         if dY.dim() == 2 and self._use_sliced(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):
             if S.sliced_t is None:
                 S.sliced_t = SlicedCSR(S.src, S.dst, S.n_src, S.n_dst)
-            return S.sliced_t.spmm(dY, dst_scale, src_scale, out, vals=self._vals_for("sliced_t", S.sliced_t.eid))
+            return S.sliced_t.spmm(dY, dst_scale, src_scale, out, vals=self._vals_for("sliced_t", S.sliced_t.eid),
+                                   keep=self._keep)
         if dY.dim() == 2 and self._use_split(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):
             if S.split_t is None:
                 S.split_t = _SplitSliced(indptr_t, eid_t, S.dst, S.n_src, S.n_dst)
             return S.split_t.spmm(dY, _prep_scale(dst_scale, S.n_dst, "dst_scale"), _prep_scale(src_scale, S.n_src, "src_scale"),
-                                  out, self._vals_for("split_t", S.split_t.sliced.eid))
+                                  out, self._vals_for("split_t", S.split_t.sliced.eid), keep=self._keep)
         return self._run(indptr_t, indices_t, self._vals_for("csr_t", eid_t), plan_t, S.n_src, S.n_dst, dY,
-                         dst_scale, src_scale, out)
+                         dst_scale, src_scale, out, eid_t)
 
 
 class _SpMM(torch.autograd.Function):
@@ -781,6 +777,33 @@ def gather_add(pairs: EdgePairs, A: torch.Tensor, B: torch.Tensor, bias: Optiona
 # ---------------------------------------------------------------------------------------------
 # (D3) edge-dropout selection — augmentation.py:48-52, 114-118
 # ---------------------------------------------------------------------------------------------
+def random_subset_select(E: int, keep: int, seed: int, device, e_offset: int = 0) -> torch.Tensor:
+    """The 8-word description (int32 tensor on ``device``) of a uniformly random subset of exactly
+    ``keep`` of ``E`` edges, a deterministic function of ``(seed, E, keep)``
+    (``dgmi_random_subset_select``): what ``CSRGraph.dropped`` and the kernels consume.  Nothing of
+    size E is written and nothing synchronises."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("dream_gnn_amd ops run on the MI355X only: got device %s" % device)
+    desc = torch.empty(8, dtype=torch.int32, device=device)
+    nbytes = int(_L.dgmi_random_subset_workspace_bytes())
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    with _guard(device):
+        _lib.check(_L.dgmi_random_subset_select(E, keep, seed & 0xFFFFFFFFFFFFFFFF, e_offset, _ptr(desc), _ptr(ws), nbytes,
+                                                _stream(device)), "dgmi_random_subset_select")
+    return desc
+
+
+def keep_mask(desc: torch.Tensor, E: int) -> torch.Tensor:
+    """float 0/1 mask over edges [0, E) under the subset description(s) ``desc`` (``dgmi_keep_mask_f32``)."""
+    desc = _prep_keep(desc)
+    dev = _require_device(desc)
+    mask = torch.empty(E, dtype=torch.float32, device=dev)
+    with _guard(dev):
+        _lib.check(_L.dgmi_keep_mask_f32(_ptr(desc), int(desc.shape[0]), E, _ptr(mask), _stream(dev)), "dgmi_keep_mask_f32")
+    return mask
+
+
 def random_subset_mask(E: int, keep: int, seed: int, device) -> torch.Tensor:
     """float 0/1 mask over E edges with exactly ``keep`` ones, a uniformly random subset that is a
     deterministic function of ``(seed, E, keep)`` (``dgmi_random_subset_mask_f32``)."""

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 8
+#define DGMI_ABI_VERSION 9
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -110,9 +110,19 @@ DGMI_API int dgmi_csr_from_coo_i32(const int32_t* row, const int32_t* col, int64
  * result is bitwise reproducible from run to run (no atomics).
  * The backward of the op is the same call on the transposed CSR with the two
  * scales swapped: dX = diag(src_scale) A^T diag(dst_scale) dY.
+ *
+ * Edge dropout on the fly (all three SpMM entry points): n_keep > 0 restricts the sum to the
+ * edges that survive the reference's per-iteration edge dropout (train.py:267,
+ * augmentation.py:13-124) WITHOUT rebuilding the graph: position p takes part iff
+ * keep(eid[p]), where eid[p] is the edge's position in the caller's COO order (as produced by
+ * the layout builders) and `keep` holds n_keep (<= 8) eight-word descriptions written by
+ * dgmi_random_subset_select (one per independently dropped edge list; several when a layout
+ * concatenates relations).  Dropped edges are skipped — their source rows are not read into the
+ * sum, so Inf / NaN there do not leak (unlike a 0/1 value mask).  n_keep == 0: eid, keep unused.
  */
 DGMI_API int dgmi_spmm_csr_f32(const int32_t* indptr, const int32_t* indices,
-                      const float* vals, const float* X, int64_t ldx,
+                      const float* vals, const int32_t* eid, const uint32_t* keep, int32_t n_keep,
+                      const float* X, int64_t ldx,
                       const float* src_scale, const float* dst_scale, float* Y,
                       int64_t ldy, int64_t n_dst, int64_t n_src, int64_t F,
                       dgmi_stream_t stream);
@@ -144,7 +154,8 @@ DGMI_API int dgmi_spmm_plan_build(const int32_t* indptr, int64_t n_rows, int64_t
                                   int32_t chunk, void* plan, size_t plan_bytes, void* workspace,
                                   size_t* workspace_bytes, dgmi_stream_t stream);
 DGMI_API int dgmi_spmm_csr_planned_f32(const int32_t* indptr, const int32_t* indices,
-                                       const float* vals, const float* X, int64_t ldx,
+                                       const float* vals, const int32_t* eid, const uint32_t* keep,
+                                       int32_t n_keep, const float* X, int64_t ldx,
                                        const float* src_scale, const float* dst_scale, float* Y,
                                        int64_t ldy, int64_t n_dst, int64_t n_src, int64_t F,
                                        int64_t nnz, int32_t chunk, const void* plan,
@@ -183,63 +194,11 @@ DGMI_API int dgmi_csr_sliced_from_coo_i32(const int32_t* row, const int32_t* col
                                           dgmi_stream_t stream);
 DGMI_API size_t dgmi_spmm_sliced_planes_bytes(int64_t n_dst, int32_t n_slices, int64_t F);
 DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices, const float* vals,
+                                  const int32_t* eid, const uint32_t* keep, int32_t n_keep,
                                   const float* X, int64_t ldx, const float* src_scale,
                                   const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
                                   int64_t n_src, int64_t F, int32_t n_slices, void* planes,
                                   size_t planes_bytes, dgmi_stream_t stream);
-
-/* -------------------------------------------------------------------------
- * Row-owned, slice-swept SpMM: the same product (B-i / B-ii) with no partial planes.
- *
- * Every lane group of the launch owns a few destination rows, keeps their running sums in LDS and
- * sweeps the source slices of X in order, so that at any time an XCD's gathers fall into one or
- * two L2-sized slices; Y is written once.  All workgroups are co-resident (grid = #CUs x
- * blocks_per_cu) — a speed assumption only.  In-row order: slice by slice, input order inside a
- * slice (deterministic; not the plain CSR's order).
- *
- *   dgmi_owned_geometry          host-only: how rows map to groups for (n_rows, n_cols, F).
- *                                blocks_per_cu <= 0 and n_slices <= 0 pick the defaults (5 and
- *                                ceil(n_cols * 4F / 3200 KiB)).  Returns DGMI_ERR_INVALID_ARG when the
- *                                shape is not eligible: F % 4 != 0, F > 256 or n_cols >= 2^27.
- *   dgmi_csr_owned_from_coo_i32  workspace protocol and error flag as dgmi_csr_from_coo_i32.
- *                                seg_ptr[geom.n_groups * geom.n_slices + 1]: first edge of (group,
- *                                slice); words[E] = src | local_row << 27; eid[E] maps layout
- *                                positions to the caller's edge order.
- *   dgmi_spmm_owned_f32          vals (nullable) are in layout order; requires ldx % 4 == 0,
- *                                ldy % 4 == 0, 16-B aligned X / Y and the geometry the layout was
- *                                built with (same F class: geom.lanes_per_row covers F / 4).
- *                                progress (nullable): dgmi_spmm_owned_progress_bytes(geom) bytes of
- *                                device scratch; when given (and 1 < n_slices <= lanes_per_row) the
- *                                groups pace each other slice by slice through counters in it —
- *                                a speed aid (L2 residency of the live slice), zeroed by the call.
- */
-typedef struct dgmi_owned_geom {
-  int32_t n_groups;         /* rounds * groups_per_round */
-  int32_t n_slices;
-  int32_t rmax;             /* most rows a group owns (<= 32) */
-  int32_t rows_lo;          /* n_rows / n_groups */
-  int32_t extra;            /* n_rows % n_groups: the first `extra` groups own rows_lo + 1 rows */
-  int32_t slice_width;      /* source ids per slice */
-  int32_t groups_per_round; /* #CUs * blocks_per_cu * groups per block */
-  int32_t rounds;
-  int32_t lanes_per_row;    /* 8 / 16 / 32 / 64 lanes, 16 B each */
-  int32_t blocks;           /* grid size: #CUs * blocks_per_cu */
-  int32_t lds_bytes;        /* dynamic LDS per block */
-  int32_t reserved;
-} dgmi_owned_geom;
-
-DGMI_API int dgmi_owned_geometry(int64_t n_rows, int64_t n_cols, int64_t F, int32_t blocks_per_cu,
-                                 int32_t n_slices, dgmi_owned_geom* geom /* host */);
-DGMI_API int dgmi_csr_owned_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
-                                         int64_t n_rows, int64_t n_cols, const dgmi_owned_geom* geom /* host */,
-                                         int32_t* seg_ptr, uint32_t* words, int32_t* eid, void* workspace,
-                                         size_t* workspace_bytes, dgmi_stream_t stream);
-DGMI_API size_t dgmi_spmm_owned_progress_bytes(const dgmi_owned_geom* geom /* host */);
-DGMI_API int dgmi_spmm_owned_f32(const int32_t* seg_ptr, const uint32_t* words, const float* vals,
-                                 const float* X, int64_t ldx, const float* src_scale,
-                                 const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
-                                 int64_t n_src, int64_t F, const dgmi_owned_geom* geom /* host */,
-                                 void* progress, size_t progress_bytes, dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
  * (f2) Per-edge gather-concat: out[e, 0:Fa] = A[src[e], :], out[e, Fa:Fa+Fb] = B[dst[e], :].
@@ -269,14 +228,27 @@ DGMI_API int dgmi_gather_add_f32(const int32_t* src, const int32_t* dst, int64_t
                                  int64_t F, float* out, int64_t ldo, dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
- * (D3) Edge dropout selection: mask[e] = 1.0f for a uniformly random subset of exactly `keep`
- * of the E edges, 0.0f elsewhere — what `perm = randperm(E); keep = perm[:num_keep]`
- * (augmentation.py:48-52, 114-118) selects, without materialising the permutation: per-edge
- * keys (hash32(seed, e), e), 4-pass radix select of the keep-th smallest, one mask pass.
+ * (D3) Edge dropout selection: a uniformly random subset of exactly `keep` of E edges — what
+ * `perm = randperm(E); keep = perm[:num_keep]` (augmentation.py:48-52, 114-118) selects,
+ * without materialising the permutation: per-edge keys (hash32(seed, e), e), a 4-pass radix
+ * select of the keep-th smallest, one pass that orders equal hashes by edge id.
  * Deterministic in (seed, E, keep).  workspace: dgmi_random_subset_workspace_bytes() bytes.
  * 0 <= keep <= E.
+ *
+ *   dgmi_random_subset_select   writes the subset's 8-word description to desc[0..7] (device):
+ *                               {e_begin = e_offset, e_end = e_offset + E, seed_lo, seed_hi,
+ *                               threshold hash, tie cut, 0, 0}; edge e_offset + i is kept iff
+ *                               hash32(seed, i) < thr || (hash32(seed, i) == thr && i <= tie cut).
+ *                               This is what the SpMM entry points take as `keep`.
+ *   dgmi_keep_mask_f32          mask[e] = 1.0f / 0.0f for e in [0, E) under n_keep descriptions.
+ *   dgmi_random_subset_mask_f32 both in one call (e_offset = 0).
  */
 DGMI_API size_t dgmi_random_subset_workspace_bytes(void);
+DGMI_API int dgmi_random_subset_select(int64_t E, int64_t keep, uint64_t seed, uint32_t e_offset,
+                                       uint32_t* desc, void* workspace, size_t workspace_bytes,
+                                       dgmi_stream_t stream);
+DGMI_API int dgmi_keep_mask_f32(const uint32_t* keep, int32_t n_keep, int64_t E, float* mask,
+                                dgmi_stream_t stream);
 DGMI_API int dgmi_random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask,
                                          void* workspace, size_t workspace_bytes,
                                          dgmi_stream_t stream);

@@ -116,30 +116,6 @@ def csr_sliced_from_coo(row, col, n_rows, n_cols, n_slices):
     return np.cumsum(segptr).astype(np.int32), col[order].astype(np.int32), order.astype(np.int32)
 
 
-def csr_owned_from_coo(row, col, n_rows, n_cols, geom):
-    """Row-owned layout of ``dgmi_csr_owned_from_coo_i32`` (dream_gnn_amd/csrc/dgmi_owned.hip):
-    rows are dealt evenly over ``n_groups`` lane groups (the first ``extra`` own ``rows_lo + 1``),
-    edges sorted stably by ``(group(row) * n_slices + slice(col)) * rmax + local_row``.
-    ``geom``: anything with the fields of ``dgmi_owned_geom``.  Returns (seg_ptr, words, eid) with
-    ``seg_ptr[g * n_slices + s]`` the first edge of (group g, slice s)."""
-    row = np.asarray(row, np.int64)
-    col = np.asarray(col, np.int64)
-    G, S, rmax, lo, extra, width = (int(getattr(geom, k)) for k in
-                                    ("n_groups", "n_slices", "rmax", "rows_lo", "extra", "slice_width"))
-    big = extra * (lo + 1)
-    in_big = row < big
-    q = (row - big) // max(lo, 1)
-    g = np.where(in_big, row // (lo + 1), extra + q)
-    lrow = np.where(in_big, row - (row // (lo + 1)) * (lo + 1), (row - big) - q * lo)
-    sl = np.minimum(col // width, S - 1)
-    key = (g * S + sl) * rmax + lrow
-    order = np.argsort(key, kind="stable")
-    seg_ptr = np.zeros(G * S + 1, np.int64)
-    np.add.at(seg_ptr, g * S + sl + 1, 1)
-    words = (col[order] | (lrow[order] << 27)).astype(np.uint32)
-    return np.cumsum(seg_ptr).astype(np.int32), words, order.astype(np.int32)
-
-
 def spmm_csr(indptr, indices, vals, X, src_scale=None, dst_scale=None, threads=1, acc="f32", validate=True):
     """``Y = diag(dst_scale) A diag(src_scale) X`` over a CSR; ``vals=None`` is
     ``update_all(copy_u, sum)`` (layers.py:229-232), else ``th.spmm`` (layers.py:312).
@@ -263,20 +239,64 @@ def similarity_graph_coo(sim, k, symm=True):
     return norm.row.astype(np.int64), norm.col.astype(np.int64), norm.data.astype(np.float32), n
 
 
-def random_subset_mask(E, keep, seed):
-    """Restatement of ``dgmi_random_subset_mask_f32``: keys (hash32(seed, e), e) with the
-    splitmix64 finaliser; the ``keep`` smallest keys are kept.  The subset it stands for is the
-    reference's ``randperm(E)[:num_keep]`` (augmentation.py:48-52): uniformly random, exact size."""
+def _edge_hash(seed, E):
+    """hash32(seed, e) for e in [0, E): the splitmix64 finaliser of dream_gnn_amd/csrc/dgmi_keep.h."""
     with np.errstate(over="ignore"):
         e = np.arange(E, dtype=np.uint64)
         z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + (e + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
-    h = (z >> np.uint64(32)).astype(np.uint64)
+    return (z >> np.uint64(32)).astype(np.uint64)
+
+
+def random_subset_mask(E, keep, seed):
+    """Restatement of ``dgmi_random_subset_mask_f32``: keys (hash32(seed, e), e) with the
+    splitmix64 finaliser; the ``keep`` smallest keys are kept.  The subset it stands for is the
+    reference's ``randperm(E)[:num_keep]`` (augmentation.py:48-52): uniformly random, exact size."""
+    h = _edge_hash(seed, E)
     order = np.lexsort((np.arange(E), h))  # by hash, ties by edge id
     mask = np.zeros(E, np.float32)
     mask[order[:keep]] = 1.0
+    return mask
+
+
+def random_subset_select(E, keep, seed, e_offset=0):
+    """Restatement of ``dgmi_random_subset_select``: the 8-word description of the same subset —
+    {e_begin, e_end, seed_lo, seed_hi, threshold hash, tie cut, 0, 0} as int32 bit patterns:
+    edge ``e_offset + i`` is kept iff ``hash(i) < thr or (hash(i) == thr and i <= tie_cut)``."""
+    h = _edge_hash(seed, E)
+    thr, tie_cut = 0, -1
+    if keep > 0:
+        order = np.lexsort((np.arange(E), h))
+        last = int(order[keep - 1])
+        thr = int(h[last])
+        ties_kept = keep - int((h < thr).sum())
+        tie_ids = np.flatnonzero(h == thr)
+        tie_cut = int(tie_ids[ties_kept - 1]) if ties_kept > 0 else -1
+        assert tie_cut == last or ties_kept == 0
+    seed &= 0xFFFFFFFFFFFFFFFF
+    words = np.array([e_offset, e_offset + E, seed & 0xFFFFFFFF, seed >> 32, thr, tie_cut & 0xFFFFFFFF, 0, 0], np.uint64)
+    return words.astype(np.uint32).view(np.int32)
+
+
+def keep_mask(desc, E):
+    """Restatement of ``dgmi_keep_mask_f32``: float 0/1 over edges [0, E) under (n, 8) descriptions;
+    edges outside every description are kept."""
+    d = np.asarray(desc, np.int32).reshape(-1, 8).view(np.uint32).astype(np.uint64)
+    mask = np.ones(E, np.float32)
+    claimed = np.zeros(E, bool)
+    for e_begin, e_end, lo, hi, thr, cut, _, _ in d:
+        e_begin, e_end = int(e_begin), min(int(e_end), E)
+        if e_end <= e_begin:
+            continue
+        n = e_end - e_begin
+        h = _edge_hash((int(hi) << 32) | int(lo), n)
+        cut = int(np.uint32(cut).view(np.int32)) if isinstance(cut, np.generic) else int(np.array(cut, np.uint32).view(np.int32))
+        kept = (h < thr) | ((h == thr) & (np.arange(n) <= cut))
+        sel = ~claimed[e_begin:e_end]  # first matching description wins, as in the kernel
+        mask[e_begin:e_end][sel] = kept[sel].astype(np.float32)
+        claimed[e_begin:e_end] = True
     return mask
 
 

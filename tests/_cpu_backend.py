@@ -62,7 +62,19 @@ def random_subset_mask(E, keep, seed, device):
     return torch.from_numpy(O.random_subset_mask(E, keep, seed))
 
 
-def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx):
+def random_subset_select(E, keep, seed, device, e_offset=0):
+    return torch.from_numpy(O.random_subset_select(E, keep, seed, e_offset).copy())
+
+
+def keep_mask(desc, E):
+    return torch.from_numpy(O.keep_mask(desc.numpy(), E))
+
+
+def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx,
+                 eid=None, keep=None):
+    if keep is not None:  # edge dropout on the fly: position p takes part iff keep(eid[p])
+        m = keep_mask(keep, int(eid.max()) + 1 if eid.numel() else 0)[eid.long()]
+        vals = m if vals is None else vals * m
     return spmm_csr_raw(indptr, indices, vals, X, src_scale, dst_scale, out=out)
 
 
@@ -71,13 +83,15 @@ def patched():
     from dream_gnn_amd import ops
 
     names = ("csr_from_coo", "gather_f32", "spmm_csr_raw", "_launch_spmm", "_require_device", "build_plan", "FORCE_KERNEL",
-             "gather_concat_raw", "gather_add_raw", "random_subset_mask")
+             "gather_concat_raw", "gather_add_raw", "random_subset_mask", "random_subset_select", "keep_mask")
     saved = {k: getattr(ops, k) for k in names}
     ops.csr_from_coo, ops.gather_f32, ops.spmm_csr_raw = csr_from_coo, gather_f32, spmm_csr_raw
     ops._launch_spmm = _launch_spmm
     ops.gather_concat_raw = gather_concat_raw
     ops.gather_add_raw = gather_add_raw
     ops.random_subset_mask = random_subset_mask
+    ops.random_subset_select = random_subset_select
+    ops.keep_mask = keep_mask
     ops._require_device = lambda *ts: next((t.device for t in ts if t is not None), None)
     ops.build_plan = lambda indptr, nnz, chunk=None: None  # launch plans are a device-side concern
     ops.FORCE_KERNEL = "planned"  # the sliced layout is a device-side concern too

@@ -18,7 +18,8 @@ def _declared():
 def test_header_declares_the_expected_entry_points():
     assert _declared() == ["dgmi_abi_version", "dgmi_csr_from_coo_i32", "dgmi_csr_sliced_from_coo_i32",
                            "dgmi_device_ok", "dgmi_gather_add_f32", "dgmi_gather_concat_f32",
-                           "dgmi_gather_f32", "dgmi_random_subset_mask_f32", "dgmi_random_subset_workspace_bytes",
+                           "dgmi_gather_f32", "dgmi_keep_mask_f32", "dgmi_probe_row_gather_f32",
+                           "dgmi_random_subset_mask_f32", "dgmi_random_subset_select", "dgmi_random_subset_workspace_bytes",
                            "dgmi_spmm_csr_f32", "dgmi_spmm_csr_planned_f32", "dgmi_spmm_default_chunk",
                            "dgmi_spmm_partials_bytes", "dgmi_spmm_plan_build", "dgmi_spmm_plan_bytes",
                            "dgmi_spmm_sliced_f32", "dgmi_spmm_sliced_planes_bytes", "dgmi_status_string"]
@@ -52,11 +53,19 @@ def test_argument_validation_returns_codes_without_a_gpu():
     assert L.dgmi_csr_from_coo_i32(None, None, -1, 4, 0, None, None, None, None, ctypes.byref(need), None) == -1
     assert L.dgmi_csr_from_coo_i32(None, None, 1, 4, 0, None, None, None, None, None, None) == -1
     assert L.dgmi_csr_from_coo_i32(None, None, 2 ** 31, 4, 0, None, None, None, None, ctypes.byref(need), None) == -2
-    assert L.dgmi_spmm_csr_f32(None, None, None, None, 4, None, None, None, 4, -1, 1, 4, None) == -1
-    assert L.dgmi_spmm_csr_f32(None, None, None, None, 4, None, None, None, 4, 2, 2, 4, None) == -1  # null indptr/Y
-    assert L.dgmi_spmm_csr_f32(None, None, None, None, 4, None, None, None, 4, 0, 0, 4, None) == 0   # empty problem
-    assert L.dgmi_spmm_csr_f32(16, 16, None, 16, 2, None, None, 32, 4, 2, 2, 4, None) == -1          # ldx < F
-    assert L.dgmi_spmm_csr_f32(16, 16, None, 64, 4, None, None, 64, 4, 2, 2, 4, None) == -1          # Y aliases X
+    K0 = (None, None, 0)  # no edge dropout on the fly: eid, keep, n_keep
+    assert L.dgmi_spmm_csr_f32(None, None, None, *K0, None, 4, None, None, None, 4, -1, 1, 4, None) == -1
+    assert L.dgmi_spmm_csr_f32(None, None, None, *K0, None, 4, None, None, None, 4, 2, 2, 4, None) == -1  # null indptr/Y
+    assert L.dgmi_spmm_csr_f32(None, None, None, *K0, None, 4, None, None, None, 4, 0, 0, 4, None) == 0   # empty problem
+    assert L.dgmi_spmm_csr_f32(16, 16, None, *K0, 16, 2, None, None, 32, 4, 2, 2, 4, None) == -1          # ldx < F
+    assert L.dgmi_spmm_csr_f32(16, 16, None, *K0, 64, 4, None, None, 64, 4, 2, 2, 4, None) == -1          # Y aliases X
+    assert L.dgmi_spmm_csr_f32(16, 16, None, None, 16, 1, 16, 4, None, None, 32, 4, 2, 2, 4, None) == -1  # keep without eid
+    assert L.dgmi_spmm_csr_f32(16, 16, None, 16, 16, 9, 16, 4, None, None, 32, 4, 2, 2, 4, None) == -1    # > 8 descriptions
+    assert L.dgmi_random_subset_select(10, 11, 0, 0, 16, 16, 1 << 20, None) == -1                         # keep > E
+    assert L.dgmi_random_subset_select(10, 5, 0, 0, 16, 16, 8, None) == -3                                # workspace too small
+    assert L.dgmi_random_subset_select(10, 5, 0, 2 ** 31 - 5, 16, 16, 1 << 20, None) == -2                # offset + E overflows
+    assert L.dgmi_keep_mask_f32(None, 1, 5, 16, None) == -1 and L.dgmi_keep_mask_f32(None, 0, 0, None, None) == 0
+    assert L.dgmi_probe_row_gather_f32(16, 8, 6, 8, 8, 8, 0, 16, None) == -1                              # F % 4
     # plan sizing is host arithmetic: items <= n_rows + nnz/chunk, long rows <= nnz/(chunk+1)
     assert L.dgmi_spmm_default_chunk(50_000, 10_000_000) == 512
     assert L.dgmi_spmm_default_chunk(681, 465_000) == 128
@@ -67,8 +76,8 @@ def test_argument_validation_returns_codes_without_a_gpu():
     assert L.dgmi_spmm_partials_bytes(1000, 64, 341) == (15 + 15) * 344 * 4
     assert L.dgmi_spmm_partials_bytes(0, 64, 128) == 16
     assert L.dgmi_spmm_plan_build(None, -1, 0, 64, None, 0, None, ctypes.byref(need), None) == -1
-    assert L.dgmi_spmm_csr_planned_f32(16, 16, None, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 7, 16, 16, 1 << 20, None) == -1
-    assert L.dgmi_spmm_csr_planned_f32(16, 16, None, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 64, 16, 16, 0, None) == -3
+    assert L.dgmi_spmm_csr_planned_f32(16, 16, None, *K0, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 7, 16, 16, 1 << 20, None) == -1
+    assert L.dgmi_spmm_csr_planned_f32(16, 16, None, *K0, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 64, 16, 16, 0, None) == -3
     assert L.dgmi_gather_concat_f32(None, None, -1, None, 4, 4, None, 4, 4, None, 8, None) == -1
     assert L.dgmi_gather_concat_f32(16, 16, 3, 16, 4, 4, 16, 4, 4, 16, 7, None) == -1  # ldo < Fa+Fb
     assert L.dgmi_gather_concat_f32(None, None, 0, None, 4, 4, None, 4, 4, None, 8, None) == 0

@@ -69,8 +69,6 @@ def test_lrssl_slices_every_row_every_kernel(oracle, lrssl, dev, F):
                  "CSRGraph.spmm (the form the modules call)": g.spmm(Xd, cj, ci)}
         if F % 4 == 0:
             forms["xcd-sliced"] = ops.SlicedCSR(rel.dst, rel.src, rel.n_dst, rel.n_src).spmm(Xd, cj, ci)
-            if hasattr(ops, "OwnedCSR"):
-                forms["row-owned"] = ops.OwnedCSR(rel.dst, rel.src, rel.n_dst, rel.n_src).spmm(Xd, cj, ci)
         for name, y in forms.items():
             _all_rows_vs_oracle(oracle, indptr, indices, None, X, cj.cpu().numpy(), ci.cpu().numpy(), y,
                                 "%s %s F=%d" % (can[1], name, F))

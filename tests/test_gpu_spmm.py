@@ -299,87 +299,6 @@ def test_xcd_sliced_edge_cases(oracle, dev):
     assert np.abs(y - y64).max() <= 1e-5 * np.abs(y64).max()
 
 
-@pytest.mark.parametrize("F", [4, 32, 64, 128, 256])
-@pytest.mark.parametrize("mode", ["copy_u", "all"])
-@pytest.mark.parametrize("shape", [(203, 157, 7000, 0), (203, 157, 7000, 5), (9, 1000, 4000, 3), (40, 30, 0, 0)])
-def test_row_owned_spmm_vs_oracle(oracle, dev, F, mode, shape):
-    """The row-owned, slice-swept path: layout bit-exact vs its numpy restatement (group pointers,
-    packed edge words, eid), product within 1e-5 of the f64 oracle, every row (fewer rows than lane
-    groups here: most groups own nothing, the others one row)."""
-    from dream_gnn_amd import ops
-
-    n_dst, n_src, E, n_slices = shape
-    rng = np.random.default_rng(F + n_dst + n_slices)
-    dst, src = _rand_graph(rng, n_dst, n_src, E) if E else (np.zeros(0, np.int32), np.zeros(0, np.int32))
-    X = rng.standard_normal((n_src, F)).astype(np.float32)
-    vals = rng.standard_normal(E).astype(np.float32) if mode == "all" else None
-    ss = rng.uniform(0.1, 1.0, n_src).astype(np.float32) if mode == "all" else None
-    ds = rng.uniform(0.1, 1.0, n_dst).astype(np.float32) if mode == "all" else None
-    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
-    ow = ops.OwnedCSR(t(dst), t(src), n_dst, n_src, F=F, vals=t(vals), n_slices=n_slices)
-    assert int(ow._flag.item()) == 0
-    seg_ptr, words, eid = oracle.csr_owned_from_coo(dst, src, n_dst, n_src, ow.geom)
-    assert np.array_equal(ow.seg_ptr.cpu().numpy(), seg_ptr)
-    assert np.array_equal(ow.words.cpu().numpy().view(np.uint32), words)
-    assert np.array_equal(ow.eid.cpu().numpy(), eid)
-    y = ow.spmm(t(X), t(ss), t(ds)).cpu().numpy()
-    ip, ix, e0 = oracle.csr_from_coo(dst, src, n_dst)
-    v0 = None if vals is None else vals[e0]
-    y64 = oracle.spmm_csr(ip, ix, v0, X, ss, ds, acc="f64")
-    yabs = oracle.spmm_csr(ip, ix, v0, X, ss, ds, acc="abs")
-    assert np.all(np.abs(y - y64) <= RTOL * yabs + 1e-30)
-    assert np.abs(y - y64).max() <= RTOL * max(np.abs(y64).max(), 1e-30)
-    assert np.all(y[np.diff(ip) == 0] == 0)
-    assert np.array_equal(y, ow.spmm(t(X), t(ss), t(ds)).cpu().numpy())  # reproducible
-
-
-@pytest.mark.parametrize("n_dst,F", [(100_003, 128), (70_001, 256), (170_003, 64)])
-def test_row_owned_many_rows_and_rounds(oracle, dev, n_dst, F):
-    """More destination rows than one sweep's LDS holds (-> several rounds per group), uneven
-    rows per group, long and empty rows, every row against the f64 oracle."""
-    from dream_gnn_amd import ops
-
-    rng = np.random.default_rng(n_dst)
-    n_src, E = 4_001, 600_000
-    dst = rng.integers(0, n_dst, E).astype(np.int32)
-    dst[:20_000] = 77  # one long row
-    dst[dst == 5] = 6  # an empty row
-    src = rng.integers(0, n_src, E).astype(np.int32)
-    X = rng.standard_normal((n_src, F)).astype(np.float32)
-    vals = rng.standard_normal(E).astype(np.float32)
-    t = lambda a: torch.from_numpy(a).to(dev)
-    ow = ops.OwnedCSR(t(dst), t(src), n_dst, n_src, F=F, vals=t(vals), n_slices=7)
-    assert ow.geom.rounds >= 2 and ow.geom.extra > 0
-    seg_ptr, words, eid = oracle.csr_owned_from_coo(dst, src, n_dst, n_src, ow.geom)
-    assert np.array_equal(ow.seg_ptr.cpu().numpy(), seg_ptr)
-    assert np.array_equal(ow.words.cpu().numpy().view(np.uint32), words) and np.array_equal(ow.eid.cpu().numpy(), eid)
-    y = ow.spmm(t(X)).cpu().numpy()
-    ip, ix, e0 = oracle.csr_from_coo(dst, src, n_dst)
-    y64 = oracle.spmm_csr(ip, ix, vals[e0], X, acc="f64")
-    yabs = oracle.spmm_csr(ip, ix, vals[e0], X, acc="abs")
-    assert np.all(np.abs(y - y64) <= RTOL * yabs + 1e-30)
-    assert np.all(y[5] == 0)
-    # unweighted: A @ ones = degree, exactly
-    ones = ow.spmm(torch.ones(n_src, F, device=dev), vals=None).cpu().numpy()
-    assert np.array_equal(ones[:, 0], np.diff(ip).astype(np.float32)) and np.array_equal(ones[:, 0], ones[:, F - 1])
-
-
-def test_row_owned_rejects_ineligible_shapes_and_bad_ids(dev):
-    from dream_gnn_amd import ops
-
-    z = torch.zeros(4, dtype=torch.int32, device=dev)
-    for F in (6, 260, 344):
-        with pytest.raises(RuntimeError, match="not eligible"):
-            ops.OwnedCSR(z, z, 5, 3, F=F)
-    ow = ops.OwnedCSR(z, z, 5, 3, F=128)
-    with pytest.raises(RuntimeError):
-        ow.spmm(torch.randn(3, 256, device=dev))  # wider than the layout's lanes per row
-    assert torch.equal(ow.spmm(torch.ones(3, 64, device=dev)), torch.tensor([4.0] + [0.0] * 4, device=dev)[:, None].expand(5, 64))
-    bad = torch.tensor([0, 9, 1, -1], dtype=torch.int32, device=dev)
-    assert int(ops.OwnedCSR(bad, z, 5, 3, F=128)._flag.item()) == 1  # reported, arrays stay in bounds
-    assert int(ops.OwnedCSR(z, bad, 5, 3, F=128)._flag.item()) == 1
-
-
 @pytest.mark.skipif(bool(__import__("os").environ.get("DGMI_FORCE_KERNEL")), reason="kernel choice is forced")
 def test_csrgraph_picks_sliced_only_when_profitable(dev):
     from dream_gnn_amd import ops
@@ -500,7 +419,8 @@ def test_edge_dropout_select_path_no_sync_and_same_product(dev):
     hg["0"].csr, hg["rev-0"].csr  # parents validated once
     child = G.random_edge_dropout(hg, 0.1, generator=gen)
     rel = child["0"]
-    assert isinstance(rel, G.DroppedRelation) and rel._keep_idx is None  # select path: mask only, nothing read back
+    assert isinstance(rel, G.DroppedRelation) and rel._keep_idx is None and rel._mask is None  # select path: an 8-word description, nothing of size E written or read back
+    assert rel.desc is not None and tuple(rel.desc.shape) == (8,)
     assert rel.number_of_edges() == int(E * 0.9) and float(rel.keep_mask().sum()) == int(E * 0.9)
     X = torch.randn(n_d, 64, device=dev)
     rebuilt = ops.CSRGraph(rel.dst, rel.src, rel.n_dst, rel.n_src)  # materialises the kept lists (ascending)
@@ -514,3 +434,82 @@ def test_edge_dropout_select_path_no_sync_and_same_product(dev):
     assert torch.equal(m1, m2)
     lit = G.random_edge_dropout(hg, 0.3, selection="randperm")["0"]
     assert lit._keep_idx is not None and lit.number_of_edges() == int(E * 0.7)
+
+
+@pytest.mark.parametrize("E,keep,off", [(1, 1, 0), (7, 3, 5), (1000, 1, 0), (1000, 999, 17), (1000, 1000, 0), (1000, 0, 3),
+                                        (123457, 111111, 1_000_000), (2_000_003, 1_800_002, 0)])
+def test_random_subset_description_bit_exact(oracle, dev, E, keep, off):
+    """(D3) the 8-word subset description and the mask derived from it: integer work, bit-exact."""
+    from dream_gnn_amd import ops
+
+    for seed in (0, 12345678901234567, 2 ** 64 - 1):
+        d = ops.random_subset_select(E, keep, seed, dev, e_offset=off)
+        assert np.array_equal(d.cpu().numpy(), oracle.random_subset_select(E, keep, seed, off))
+        m = ops.keep_mask(d, off + E + 3).cpu().numpy()
+        assert m[:off].all() and m[off + E:].all() and m[off:off + E].sum() == keep  # outside the description: kept
+        assert np.array_equal(m[off:off + E], oracle.random_subset_mask(E, keep, seed))
+    # two descriptions over one edge space (a relation-fused layout)
+    a = ops.random_subset_select(E, keep, 5, dev, e_offset=0)
+    b = ops.random_subset_select(E, keep, 6, dev, e_offset=E)
+    both = ops.keep_mask(torch.stack([a, b]), 2 * E).cpu().numpy()
+    assert np.array_equal(both, np.concatenate([oracle.random_subset_mask(E, keep, 5), oracle.random_subset_mask(E, keep, 6)]))
+
+
+@pytest.mark.parametrize("F", [128, 64, 341, 4])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_edge_dropout_on_the_fly_every_kernel(oracle, dev, F, weighted):
+    """`keep(eid[p])` evaluated inside the kernels == the product over a graph REBUILT from the kept
+    edges (the reference's construction, augmentation.py:48-65), for every kernel form and the
+    transpose; dropped edges are skipped, so Inf in a source row that only dropped edges touch
+    does not reach the output (a 0/1 value mask would give 0 * Inf = NaN)."""
+    from dream_gnn_amd import ops
+
+    rng = np.random.default_rng(F + weighted)
+    n_dst, n_src, E = 300, 2500, 6000  # many sources of degree 1-3
+    dst = rng.integers(0, n_dst, E).astype(np.int32)
+    src = rng.integers(0, n_src, E).astype(np.int32)
+    vals = rng.standard_normal(E).astype(np.float32) if weighted else None
+    keep_n = max(1, int(E * 0.7))
+    mask = oracle.random_subset_mask(E, keep_n, 77).astype(bool)
+    kept_per_src = np.bincount(src[mask], minlength=n_src)
+    dead = np.flatnonzero((np.bincount(src, minlength=n_src) > 0) & (kept_per_src == 0))
+    assert dead.size > 50
+    X = rng.standard_normal((n_src, F)).astype(np.float32)
+    X_inf = X.copy()
+    X_inf[dead[:25]] = np.inf
+    X_inf[dead[25:50]] = np.nan
+    ss = rng.uniform(0.5, 1.5, n_src).astype(np.float32)
+    ds = rng.uniform(0.5, 1.5, n_dst).astype(np.float32)
+    ip, ix, e0 = oracle.csr_from_coo(dst[mask], src[mask], n_dst)
+    v0 = None if vals is None else vals[mask][e0]
+    ref = oracle.spmm_csr(ip, ix, v0, X, ss, ds, acc="f64")
+    bound = oracle.spmm_csr(ip, ix, v0, X, ss, ds, acc="abs")
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    g = ops.CSRGraph(t(dst), t(src), n_dst, n_src, vals=t(vals))
+    desc = ops.random_subset_select(E, keep_n, 77, dev)
+    view = g.dropped(desc)
+    assert view.indptr is g.indptr and torch.equal(view.keep_mask().cpu(), torch.from_numpy(mask.astype(np.float32)))
+    Xd, ssd, dsd = t(X_inf), t(ss), t(ds)
+    forms = {"wave-per-row": ops.spmm_csr_raw(g.indptr, g.indices, g.vals, Xd, ssd, dsd, eid=g.eid, keep=desc),
+             "planned": ops.spmm_csr_raw(g.indptr, g.indices, g.vals, Xd, ssd, dsd, plan=g.plan, eid=g.eid, keep=desc),
+             "CSRGraph view": view.spmm(Xd, ssd, dsd)}
+    if F % 4 == 0:
+        sl = ops.SlicedCSR(t(dst), t(src), n_dst, n_src, vals=t(vals))
+        forms["xcd-sliced"] = sl.spmm(Xd, ssd, dsd, keep=desc)
+    for name, y in forms.items():
+        y = y.cpu().numpy()
+        assert np.isfinite(y).all(), name
+        assert np.all(np.abs(y - ref) <= RTOL * bound + 1e-30), name
+    # transpose: dX = diag(ss) A_kept^T diag(ds) W
+    W = rng.standard_normal((n_dst, F)).astype(np.float32)
+    tp, ti, te = oracle.csr_from_coo(src[mask], dst[mask], n_src)
+    vt = None if vals is None else vals[mask][te]
+    ref_t = oracle.spmm_csr(tp, ti, vt, W, ds, ss, acc="f64")
+    bound_t = oracle.spmm_csr(tp, ti, vt, W, ds, ss, acc="abs")
+    dx = view.spmm_t(t(W), ssd, dsd).cpu().numpy()
+    assert np.all(np.abs(dx - ref_t) <= RTOL * bound_t + 1e-30)
+    assert np.all(dx[dead] == 0)
+    # autograd through the view
+    x = t(X).requires_grad_(True)
+    ops.spmm_csr(view, x, ssd, dsd).backward(t(W))
+    assert np.all(np.abs(x.grad.cpu().numpy() - ref_t) <= RTOL * bound_t + 1e-30)

@@ -210,15 +210,19 @@ def test_dgl_shaped_graph_is_accepted():
     C.close(o_dis, g["o_dis"], 1e-5, "o_dis")
 
 
-def test_edge_dropout_is_a_mask_view_with_the_same_product():
+@pytest.mark.parametrize("selection", ["randperm", "select"])
+def test_edge_dropout_is_a_mask_view_with_the_same_product(selection):
     """augmentation.py:13-124 without re-sorting: the dropped graph's product equals the product
-    over a CSR rebuilt from its (materialised) kept edge lists; same for the sparse adjacency."""
+    over a CSR rebuilt from its (materialised) kept edge lists; same for the sparse adjacency.
+    ``select``: the subset is an 8-word description evaluated per edge (CSRGraph.dropped);
+    ``randperm``: the reference's literal permutation prefix as a 0/1 value mask."""
     from dream_gnn_amd import graph as G, layers as L, ops
 
     g = C.load("gcmc_layer_shared_ini")
     enc = C.build_enc(g, CPU)
     torch.manual_seed(3)
-    child = G.random_edge_dropout(enc, 0.3)
+    child = G.random_edge_dropout(enc, 0.3, selection=selection)
+    assert all((child[c].desc is not None) == (selection == "select") for c in enc.canonical_etypes)
     X = {"drug": torch.randn(int(g["n_drug"]), 8), "disease": torch.randn(int(g["n_dis"]), 8)}
     for can in enc.canonical_etypes:
         rel, base = child[can], enc[can]
@@ -230,7 +234,16 @@ def test_edge_dropout_is_a_mask_view_with_the_same_product():
         w = torch.randn(rel.n_dst, 8)
         assert torch.allclose(rel.csr.spmm_t(w), rebuilt.spmm_t(w), atol=1e-5)
     fused_child, fused_parent = child.fused_relations("disease"), enc.fused_relations("disease")
-    assert fused_child[0].indptr is fused_parent[0].indptr and fused_child[0].vals is not None
+    assert fused_child[0].indptr is fused_parent[0].indptr
+    assert (fused_child[0].vals is not None) == (selection == "randperm")
+    # the fused (two-relation) view drops exactly the union of the two per-relation subsets
+    cans = fused_child[1]
+    want = torch.cat([child[c].keep_mask() for c in cans])
+    got = fused_child[0].keep_mask() if selection == "select" else fused_child[0]._coo_vals
+    assert torch.equal(got, want) and int(want.sum()) == sum(child[c].number_of_edges() for c in cans)
+    xf = torch.randn(fused_parent[0].n_src, 8)
+    ref = sum(child[c].csr.spmm(xf.view(-1, len(cans), 8)[:, i].contiguous()) for i, c in enumerate(cans))
+    assert torch.allclose(fused_child[0].spmm(xf), ref, atol=1e-5)
     # dropout of a dropout falls back to materialised lists
     grand = G.random_edge_dropout(child, 0.5)
     assert not isinstance(grand["0"], G.DroppedRelation) and grand["0"].number_of_edges() == max(1, int(child["0"].number_of_edges() * 0.5))
@@ -244,6 +257,13 @@ def test_edge_dropout_is_a_mask_view_with_the_same_product():
     assert view.indptr is L.adjacency_csr(adj).indptr
     assert torch.allclose(view.spmm(x), torch.spmm(dropped, x), atol=1e-6)
     assert torch.allclose(view.spmm_t(x), torch.spmm(dropped.t(), x), atol=1e-6)
+    # the view form (no sparse tensor is built): weighted adjacency x on-the-fly subset
+    v2 = G.random_edge_dropout_sparse(adj, 0.25, as_view=True, selection=selection)
+    base = L.adjacency_csr(adj)
+    keep = v2.keep_mask() if selection == "select" else (v2._coo_vals != 0).float()
+    assert int(keep.sum()) == max(1, int(base.nnz * 0.75))
+    ref = ops.CSRGraph(base._S.dst, base._S.src, nd, nd, vals=base._coo_vals * keep)
+    assert torch.allclose(v2.spmm(x), ref.spmm(x), atol=1e-6) and torch.allclose(v2.spmm_t(x), ref.spmm_t(x), atol=1e-6)
 
 
 def test_random_subset_selection_is_exact_and_uniformish(oracle):
