@@ -43,7 +43,9 @@ __device__ __forceinline__ void store_plane_row(float* p, const float4& v) {
 // grid.x = n_slices * ceil(rows / (4 waves * G groups * kRowsPerGroup)); block b: slice = b % n_slices.
 // Rows [row_begin, row_end) of every slice; plane row index is relative to row_begin.
 // KEEP: edge dropout on the fly — an edge whose keep(eid[p]) fails (dgmi_keep.h) is flagged in the sign
-// bit of its source id; its gather goes to row 0 (L1-hot) and its contribution is replaced by zeros.
+// bit of its source id; its gather repeats the group's previous row (an L1 hit — never one fixed row,
+// which would turn 10 % of all gathers into traffic on a single L2 channel) and its contribution is
+// replaced by zeros.
 template <int LPR, bool HAS_VALS, bool HAS_SS, bool KEEP>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ indices,
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
   // ids (and weights) one batch ahead of the gathers that use them
   int nxt_idx = 0;
   float nxt_w = 0.f;
+  int last_row = -1;  // KEEP: the row this group gathered last (where a dropped edge's load is parked)
   if (e_begin < e_end) {
     const int q = e_begin + glane < e_end ? e_begin + glane : e_begin;
     nxt_idx = fetch_id<KEEP>(indices, eid, keep, n_keep, q);
@@ -108,7 +111,10 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
         int idx = __shfl(my_idx, gbase + e, kWave);
         if (WEIGHTED) w[u] = __shfl(my_w, gbase + e, kWave);
         const bool dropped = KEEP && idx < 0;
-        if (KEEP) idx &= 0x7fffffff;
+        if (KEEP) {
+          idx = dropped && last_row >= 0 ? last_row : idx & 0x7fffffff;
+          last_row = idx;
+        }
         v[u] = ld4(Xc + (int64_t)idx * ldx);
         if (dropped) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       }

@@ -19,6 +19,7 @@ X (source features) is replicated on every rank, as the next layer needs all row
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -36,6 +37,38 @@ def _all_gather_into(out: torch.Tensor, inp: torch.Tensor, group=None):
         out.copy_(host_out)
         return
     dist.all_gather_into_tensor(out, inp, group=group)
+
+
+def _direct_exchange(out: torch.Tensor, y_local: torch.Tensor, bounds, rank: int, group=None):
+    """All-links exchange of the row blocks: every rank posts its block to each
+    of the other ranks and receives theirs straight into its rows of ``out`` — world-1 sends and
+    world-1 receives issued as ONE batch, which RCCL runs as a single grouped kernel driving all 7
+    xGMI links of the GPU at once (xGMI is point-to-point: a ring all-gather crosses one link per
+    step).  Blocks may have different heights (nnz-balanced bounds): no padding, no extra copy of
+    the payload.  ``out[bounds[rank]:bounds[rank+1]]`` is filled by a local copy."""
+    world = len(bounds) - 1
+    out[bounds[rank]:bounds[rank + 1]].copy_(y_local)
+    staged = dist.get_backend(group) == "gloo" and y_local.is_cuda  # CPU rehearsal with device tensors
+    src = y_local.cpu() if staged else y_local.contiguous()
+    recv_bufs, ops_ = {}, []
+    for step in range(1, world):  # pairings rotate so that no two ranks target the same peer in a step
+        to, frm = (rank + step) % world, (rank - step) % world
+        gto = dist.get_global_rank(group, to) if group is not None else to
+        gfrm = dist.get_global_rank(group, frm) if group is not None else frm
+        if bounds[rank + 1] > bounds[rank]:
+            ops_.append(dist.P2POp(dist.isend, src, gto, group))
+        if bounds[frm + 1] > bounds[frm]:
+            dst_view = out[bounds[frm]:bounds[frm + 1]]
+            buf = torch.empty(dst_view.shape, dtype=out.dtype) if staged else dst_view
+            recv_bufs[frm] = (buf, dst_view)
+            ops_.append(dist.P2POp(dist.irecv, buf, gfrm, group))
+    if ops_:
+        for req in dist.batch_isend_irecv(ops_):
+            req.wait()
+    if staged:
+        for buf, dst_view in recv_bufs.values():
+            dst_view.copy_(buf)
+    return out
 
 
 def balanced_row_bounds(degree: torch.Tensor, parts: int) -> torch.Tensor:
@@ -74,9 +107,22 @@ class RowShard:
         ds = None if dst_scale is None else dst_scale.reshape(-1)[self.lo:self.hi].contiguous()
         return self.local.spmm(X, src_scale, ds, out=out)
 
-    def gather_rows(self, y_local: torch.Tensor, group=None, out: Optional[torch.Tensor] = None):
-        """All-gather the per-rank row blocks into the full (n_dst, F) result."""
+    #: how row blocks are exchanged: "allgather" (one RCCL all_gather_into_tensor; uneven blocks are
+    #: padded) or "direct" (batched point-to-point sends to every peer — all xGMI links at once, no
+    #: padding).  Same result; bench.py times both on the real node and uses the faster.
+    exchange = os.environ.get("DGMI_EXCHANGE", "allgather")
+
+    def gather_rows(self, y_local: torch.Tensor, group=None, out: Optional[torch.Tensor] = None,
+                    exchange: Optional[str] = None):
+        """Assemble the per-rank row blocks into the full (n_dst, F) result on every rank."""
         F = y_local.shape[1]
+        exchange = exchange or self.exchange
+        if exchange not in ("allgather", "direct"):
+            raise ValueError("unknown exchange %r" % (exchange,))
+        if exchange == "direct" and self.world > 1:
+            if out is None:
+                out = torch.empty((self.n_dst, F), dtype=y_local.dtype, device=y_local.device)
+            return _direct_exchange(out, y_local, self.bounds, self.rank, group)
         even = all(self.bounds[i + 1] - self.bounds[i] == self.max_rows for i in range(self.world))
         if even:
             if out is None:

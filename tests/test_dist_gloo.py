@@ -42,7 +42,7 @@ def _graph(skew):
     return dst.astype(np.int64), src.astype(np.int64), val, X, dY, ss, ds, n_dst, n_src
 
 
-def _worker(rank, world, port, skew, q):
+def _worker(rank, world, port, skew, q, exchange="allgather"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -53,6 +53,7 @@ def _worker(rank, world, port, skew, q):
         from dream_gnn_amd import shard
         from oracle import oracle as O
 
+        shard.RowShard.exchange = exchange
         dst, src, val, X, dY, ss, ds, n_dst, n_src = _graph(skew)
         t = torch.from_numpy
         with _cpu_backend.patched():
@@ -82,12 +83,13 @@ def _worker(rank, world, port, skew, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["allgather", "direct"])
 @pytest.mark.parametrize("skew", [True, False])
-def test_sharded_spmm_world2(oracle, skew):
+def test_sharded_spmm_world2(oracle, skew, exchange):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, skew, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, skew, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -101,6 +103,41 @@ def test_sharded_spmm_world2(oracle, skew):
         assert b[1] != 32 and nnz[1] - nnz[0] <= 0.25 * sum(nnz)
     else:
         assert res[0][2] == [0, 32, 64] and nnz[0] == nnz[1]
+
+
+def _exchange_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dream_gnn_amd import shard
+
+        bounds = [0, 5, 5, 12, 13]  # uneven blocks, rank 1 owns nothing
+        F = 3
+        full = torch.arange(13 * F, dtype=torch.float32).view(13, F)
+        mine = full[bounds[rank]:bounds[rank + 1]].clone()
+        out = torch.full((13, F), -1.0)
+        shard._direct_exchange(out, mine, bounds, rank)
+        q.put((rank, bool(torch.equal(out, full))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_direct_exchange_indexing_world4():
+    """The all-links exchange (every rank posts its block to every peer, receives into its rows of
+    the result): uneven blocks and an empty one, no padding — indexing only, on gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
 
 
 def test_balanced_row_bounds_properties():

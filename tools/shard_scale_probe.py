@@ -11,7 +11,7 @@ scale = os.environ.get("SCALE", "edges")
 for world in [int(a) for a in (sys.argv[1:] or ["1", "2", "4", "8"])]:
     torch.cuda.empty_cache()
     t0 = time.perf_counter()
-    ops, build_ms, (nd, ns, E, knn_k) = bench.build_ops(0, world, dev, scale)
+    ops, build_ms, (nd, ns, E, knn_k) = bench.build_ops(torch, 0, world, dev, scale)
     torch.cuda.synchronize(); setup = time.perf_counter() - t0
     for _ in range(3):
         for op in ops: op.launch(False)

@@ -55,7 +55,7 @@ with open(os.path.join(out, tag + "_pmc_summary.csv"), "w", newline="") as fh:
     wr.writeheader()
     wr.writerows(rows)
 
-main = [r for r in rows if r["kernel"].startswith("spmm_sliced_vec4_kernel<32, false, true>")]
+main = [r for r in rows if r["kernel"].startswith("spmm_sliced_vec4_kernel<32, false, true, false>")]
 red = [r for r in rows if r["kernel"].startswith("reduce_planes_kernel<true")]
 dom = None
 if main and red:
