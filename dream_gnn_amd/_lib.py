@@ -12,6 +12,7 @@ import torch  # noqa: F401  -- must come first: libdgmi.so binds to the HIP runt
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgmi.so")
+TORCH_LIB_PATH = os.path.join(_HERE, "libdgmi_torch.so")  # the dreamgnn_mi::* dispatcher ops over the C ABI
 
 ABI_VERSION = 9
 
@@ -73,6 +74,20 @@ def _load() -> ctypes.CDLL:
 
 
 lib = _load()
+
+
+def _load_torch_ops():
+    """Register the ``dreamgnn_mi`` operator library (csrc/dgmi_torch.cpp).  The product path calls the
+    kernels through these ops; a missing library is an error, as for libdgmi.so."""
+    if not os.path.exists(TORCH_LIB_PATH):
+        raise ImportError(
+            "dream_gnn_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C dream_gnn_amd/csrc`. There is no CPU fallback." % TORCH_LIB_PATH)
+    torch.ops.load_library(TORCH_LIB_PATH)
+    return torch.ops.dreamgnn_mi
+
+
+torch_ops = _load_torch_ops()
 
 
 def check(status: int, what: str) -> None:

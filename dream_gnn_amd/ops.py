@@ -1,7 +1,11 @@
-"""Torch-facing wrappers over the C ABI (``include/dgmi.h``).
+"""Graph-level layer over the ``dreamgnn_mi`` dispatcher ops (``csrc/dgmi_torch.cpp``), which in turn
+are thin bindings of the C ABI (``include/dgmi.h``).
 
 PyTorch is plumbing here: it owns device memory and the stream; the arithmetic is
-``libdgmi.so``.  Every op requires HIP ("cuda") tensors and raises otherwise.
+``libdgmi.so``.  Every op requires HIP ("cuda") tensors and raises otherwise.  This module adds
+what a functional op cannot hold: the layouts of one graph (CSR, transposed CSR, XCD-sliced, their
+launch plans), built once and cached; the kernel choice per product; value and edge-dropout
+views; autograd at the graph level.
 
 Boundary being replaced (reference ``/root/reference/layers.py``):
   * ``graph.update_all(fn.copy_u('h','m'), fn.sum('m','h'))``  — layers.py:229-232
@@ -18,7 +22,8 @@ import torch
 
 from . import _lib
 
-_L = _lib.lib
+_L = _lib.lib          # ctypes view of the C ABI: host-only size / geometry queries
+_T = _lib.torch_ops    # torch.ops.dreamgnn_mi: the dispatcher ops the kernels are launched through
 _NULLCTX = contextlib.nullcontext()
 
 
@@ -54,29 +59,6 @@ def _require_device(*tensors):
     return dev
 
 
-def _check(t, dtype, name, ndim=None):
-    if t.dtype != dtype:
-        raise RuntimeError("%s must be %s, got %s" % (name, dtype, t.dtype))
-    if ndim is not None and t.dim() != ndim:
-        raise RuntimeError("%s must be %d-D, got shape %s" % (name, ndim, tuple(t.shape)))
-    if not t.is_contiguous():
-        raise RuntimeError("%s must be contiguous" % name)
-
-
-_SCRATCH = {}
-
-
-def _scratch(nbytes: int, dev, tag: str) -> torch.Tensor:
-    """Kernel scratch (chunk partials, partial planes): ONE buffer per (device, stream, kind), grown
-    on demand and reused by every product issued on that stream — products on a stream are ordered,
-    so they can share it, and nothing is allocated per call.  Contents are never read across calls."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, tag)
-    buf = _SCRATCH.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = _SCRATCH[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
-    return buf
-
-
 def csr_from_coo(row: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: int = 0,
                  check_range: bool = False, return_flag: bool = False):
     """Stable COO -> CSR on the device: ``(indptr[n_rows+1], indices[E], eid[E])``, all int32.
@@ -89,41 +71,19 @@ def csr_from_coo(row: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: int 
     callers that fold it into a readback of their own.  With the flag set the arrays are in bounds
     but meaningless: nothing may be derived from them.
     """
-    dev = _require_device(row, col)
-    _check(row, torch.int32, "row", 1)
-    _check(col, torch.int32, "col", 1)
-    if row.shape != col.shape:
-        raise RuntimeError("row/col length mismatch")
-    E = row.shape[0]
-    with _guard(dev):
-        indptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
-        indices = torch.empty(E, dtype=torch.int32, device=dev)
-        eid = torch.empty(E, dtype=torch.int32, device=dev)
-        need = ctypes.c_size_t(0)
-        _lib.check(_L.dgmi_csr_from_coo_i32(_ptr(row), _ptr(col), E, n_rows, n_cols, None, None, None, None,
-                                            ctypes.byref(need), None), "dgmi_csr_from_coo_i32(size query)")
-        ws = torch.empty(max(int(need.value), 256), dtype=torch.uint8, device=dev)
-        have = ctypes.c_size_t(ws.numel())
-        _lib.check(_L.dgmi_csr_from_coo_i32(_ptr(row), _ptr(col), E, n_rows, n_cols, _ptr(indptr), _ptr(indices),
-                                            _ptr(eid), _ptr(ws), ctypes.byref(have), _stream(dev)),
-                   "dgmi_csr_from_coo_i32")
-        if check_range and int(ws[:4].view(torch.int32).item()) != 0:
-            raise RuntimeError("csr_from_coo: an id is outside [0, %d) x [0, %s)"
-                               % (n_rows, n_cols if n_cols > 0 else "unchecked"))
+    _require_device(row, col)
+    indptr, indices, eid, flag = _T.csr_from_coo(row, col, n_rows, n_cols)
+    if check_range and int(flag.item()) != 0:
+        raise RuntimeError("csr_from_coo: an id is outside [0, %d) x [0, %s)"
+                           % (n_rows, n_cols if n_cols > 0 else "unchecked"))
     if return_flag:
-        return indptr, indices, eid, ws[:4].view(torch.int32).clone()
+        return indptr, indices, eid, flag
     return indptr, indices, eid
 
 
 def gather_f32(values: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
-    dev = _require_device(values, perm)
-    _check(values, torch.float32, "values", 1)
-    _check(perm, torch.int32, "perm", 1)
-    out = torch.empty(perm.shape[0], dtype=torch.float32, device=dev)
-    with _guard(dev):
-        _lib.check(_L.dgmi_gather_f32(_ptr(values), _ptr(perm), perm.shape[0], _ptr(out), _stream(dev)),
-                   "dgmi_gather_f32")
-    return out
+    _require_device(values, perm)
+    return _T.gather_f32(values, perm)
 
 
 class SpmmPlan:
@@ -135,27 +95,16 @@ class SpmmPlan:
         self.n_rows = int(indptr.shape[0] - 1)
         self.nnz = int(nnz)
         self.chunk = int(chunk) if chunk else int(_L.dgmi_spmm_default_chunk(self.n_rows, self.nnz))
-        nbytes = int(_L.dgmi_spmm_plan_bytes(self.n_rows, self.nnz, self.chunk))
-        if nbytes == 0:
+        if int(_L.dgmi_spmm_plan_bytes(self.n_rows, self.nnz, self.chunk)) == 0:
             raise RuntimeError("invalid plan parameters (chunk=%d)" % self.chunk)
-        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.buf = _T.plan_build(indptr, self.nnz, self.chunk)
         self._pbytes = {}
-        with _guard(dev):
-            need = ctypes.c_size_t(0)
-            _lib.check(_L.dgmi_spmm_plan_build(_ptr(indptr), self.n_rows, self.nnz, self.chunk, None, 0, None,
-                                               ctypes.byref(need), None), "dgmi_spmm_plan_build(size query)")
-            ws = torch.empty(max(int(need.value), 256), dtype=torch.uint8, device=dev)
-            have = ctypes.c_size_t(ws.numel())
-            _lib.check(_L.dgmi_spmm_plan_build(_ptr(indptr), self.n_rows, self.nnz, self.chunk, _ptr(self.buf),
-                                               nbytes, _ptr(ws), ctypes.byref(have), _stream(dev)),
-                       "dgmi_spmm_plan_build")
 
     def partials_bytes(self, F: int) -> int:
         b = self._pbytes.get(F)
         if b is None:
             b = self._pbytes[F] = int(_L.dgmi_spmm_partials_bytes(self.nnz, self.chunk, int(F)))
         return b
-
 
     def header(self):
         """(n_items, n_long_rows, n_slots, chunk, ...) — reads the device header back (tests)."""
@@ -166,44 +115,18 @@ def build_plan(indptr: torch.Tensor, nnz: int, chunk: Optional[int] = None) -> S
     return SpmmPlan(indptr, nnz, chunk)
 
 
-def _keep_args(eid, keep):
-    """(eid pointer, table pointer, n descriptions) of an on-the-fly edge dropout, or three nulls."""
-    if keep is None:
-        return None, None, 0
-    return eid.data_ptr(), keep.data_ptr(), int(keep.shape[0])
-
-
 def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx,
                  eid=None, keep=None):
-    """Validated arguments -> one C-ABI call on torch's current stream.  ``keep``: (n, 8) int32
-    subset descriptions (``random_subset_select``) applied through ``eid`` on the fly."""
-    p_eid, p_keep, n_keep = _keep_args(eid, keep)
-    with _guard(dev):
-        if plan is None:
-            rc = _L.dgmi_spmm_csr_f32(indptr.data_ptr(), indices.data_ptr(), _ptr(vals), p_eid, p_keep, n_keep,
-                                      X.data_ptr(), ldx, _ptr(src_scale), _ptr(dst_scale), out.data_ptr(), max(F, 1),
-                                      n_dst, n_src, F, _stream(dev))
-            if rc:
-                _lib.check(rc, "dgmi_spmm_csr_f32")
-        else:
-            pbytes = plan.partials_bytes(F)
-            partials = _scratch(pbytes, dev, "partials")
-            rc = _L.dgmi_spmm_csr_planned_f32(indptr.data_ptr(), indices.data_ptr(), _ptr(vals), p_eid, p_keep, n_keep,
-                                              X.data_ptr(), ldx, _ptr(src_scale), _ptr(dst_scale), out.data_ptr(),
-                                              max(F, 1), n_dst, n_src, F, plan.nnz, plan.chunk, plan.buf.data_ptr(),
-                                              partials.data_ptr(), pbytes, _stream(dev))
-            if rc:
-                _lib.check(rc, "dgmi_spmm_csr_planned_f32")
+    """One ``dreamgnn_mi::spmm_csr_raw`` / ``spmm_csr_out`` dispatch (-> ``dgmi_spmm_csr_f32`` or
+    ``dgmi_spmm_csr_planned_f32`` on torch's current stream; dtype / shape / device checks, output
+    and scratch allocation happen in the op).  ``keep``: (n, 8) int32 subset descriptions
+    (``random_subset_select``) applied through ``eid`` on the fly."""
+    args = (indptr, indices, vals, eid if keep is not None else None, keep, X, src_scale, dst_scale,
+            None if plan is None else plan.buf, 0 if plan is None else plan.chunk)
+    if out is None:
+        return _T.spmm_csr_raw(*args)
+    _T.spmm_csr_out(*args, out)
     return out
-
-
-def _prep_dense(X):
-    if X.dtype != torch.float32 or X.dim() != 2:
-        raise RuntimeError("X must be a 2-D float32 tensor, got %s %s" % (X.dtype, tuple(X.shape)))
-    if X.stride(1) != 1 or (X.shape[0] > 1 and X.stride(0) < X.shape[1]):
-        X = X.contiguous()
-    n_src, F = X.shape
-    return X, n_src, F, (X.stride(0) if n_src > 1 else max(F, 1))
 
 
 def _prep_scale(s, n, name):
@@ -222,33 +145,19 @@ def _prep_scale(s, n, name):
 
 def spmm_csr_raw(indptr, indices, vals, X, src_scale=None, dst_scale=None, out=None,
                  plan: Optional[SpmmPlan] = None, eid=None, keep=None) -> torch.Tensor:
-    """One SpMM launch through the C ABI, no autograd.  X may be a row-strided 2-D view.
-    ``plan=None``: ``dgmi_spmm_csr_f32`` (a wave per row); else ``dgmi_spmm_csr_planned_f32``.
-    ``keep`` (with ``eid``): subset descriptions for edge dropout on the fly."""
+    """One SpMM launch, no autograd.  X may be a row-strided 2-D view.  ``plan=None``:
+    ``dgmi_spmm_csr_f32`` (a wave per row); else ``dgmi_spmm_csr_planned_f32``.  ``keep`` (with
+    ``eid``): subset descriptions for edge dropout on the fly."""
     dev = _require_device(indptr, indices, vals, X, src_scale, dst_scale, out, eid, keep)
     if keep is not None:
         keep = _prep_keep(keep)
-        if eid is None or eid.shape[0] != indices.shape[0]:
-            raise RuntimeError("edge dropout on the fly needs the layout's eid array")
-    _check(indptr, torch.int32, "indptr", 1)
-    _check(indices, torch.int32, "indices", 1)
-    X, n_src, F, ldx = _prep_dense(X)
     n_dst = indptr.shape[0] - 1
-    if vals is not None:
-        _check(vals, torch.float32, "vals", 1)
-        if vals.shape[0] != indices.shape[0]:
-            raise RuntimeError("vals/indices length mismatch")
-    src_scale = _prep_scale(src_scale, n_src, "src_scale")
-    dst_scale = _prep_scale(dst_scale, n_dst, "dst_scale")
-    if out is None:
-        out = torch.empty((n_dst, F), dtype=torch.float32, device=dev)
-    else:
-        _check(out, torch.float32, "out", 2)
-        if tuple(out.shape) != (n_dst, F):
-            raise RuntimeError("out has shape %s, expected %s" % (tuple(out.shape), (n_dst, F)))
     if plan is not None and (plan.n_rows != n_dst or plan.nnz != indices.shape[0]):
         raise RuntimeError("plan was built for another CSR")
-    return _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx, eid, keep)
+    src_scale = None if src_scale is None else src_scale.reshape(-1)
+    dst_scale = None if dst_scale is None else dst_scale.reshape(-1)
+    return _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, X.shape[0],
+                        X.shape[1] if X.dim() == 2 else 0, 0, eid, keep)
 
 
 def _prep_keep(keep):
@@ -275,26 +184,13 @@ class SlicedCSR:
     N_SLICES = 8  # one slice of X per XCD
 
     def __init__(self, dst, src, n_dst, n_src, vals=None, n_slices: int = N_SLICES):
-        dev = _require_device(dst, src, vals)
+        _require_device(dst, src, vals)
         self.n_dst, self.n_src, self.n_slices = int(n_dst), int(n_src), int(n_slices)
-        E = dst.shape[0]
-        with _guard(dev):
-            self.segptr = torch.empty(self.n_slices * self.n_dst + 1, dtype=torch.int32, device=dev)
-            self.indices = torch.empty(E, dtype=torch.int32, device=dev)
-            self.eid = torch.empty(E, dtype=torch.int32, device=dev)
-            need = ctypes.c_size_t(0)
-            _lib.check(_L.dgmi_csr_sliced_from_coo_i32(_ptr(dst), _ptr(src), E, self.n_dst, self.n_src, self.n_slices,
-                                                       None, None, None, None, ctypes.byref(need), None),
-                       "dgmi_csr_sliced_from_coo_i32(size query)")
-            ws = torch.empty(max(int(need.value), 256), dtype=torch.uint8, device=dev)
-            have = ctypes.c_size_t(ws.numel())
-            _lib.check(_L.dgmi_csr_sliced_from_coo_i32(_ptr(dst), _ptr(src), E, self.n_dst, self.n_src, self.n_slices,
-                                                       _ptr(self.segptr), _ptr(self.indices), _ptr(self.eid),
-                                                       _ptr(ws), ctypes.byref(have), _stream(dev)),
-                       "dgmi_csr_sliced_from_coo_i32")
+        # range_flag: 1 if an id was out of range (device tensor; callers that build from unvalidated
+        # edge lists read it — CSRGraph validates before it ever builds this layout)
+        self.segptr, self.indices, self.eid, self.range_flag = _T.csr_sliced_from_coo(dst, src, self.n_dst, self.n_src,
+                                                                                    self.n_slices)
         self.vals = None if vals is None else gather_f32(vals, self.eid)
-        self._pbytes = {}
-        self.range_flag = ws[:4].view(torch.int32).clone()  # 1 if an id was out of range (device; not read here)
 
     _DEFAULT = object()
 
@@ -302,29 +198,16 @@ class SlicedCSR:
         """``vals`` (in sliced order, see ``eid``) overrides the values given at construction;
         ``keep``: subset descriptions applied through ``eid`` (edge dropout on the fly)."""
         vals = self.vals if vals is SlicedCSR._DEFAULT else vals
-        dev = self.segptr.device
-        p_eid, p_keep, n_keep = _keep_args(self.eid, None if keep is None else _prep_keep(keep))
-        if not X.is_cuda or X.device != dev:
+        if not X.is_cuda or X.device != self.segptr.device:
             _require_device(self.segptr, X)
-        X, n_x, F, ldx = _prep_dense(X)
-        if n_x != self.n_src:
-            raise RuntimeError("X has %d rows, the graph has %d source nodes" % (n_x, self.n_src))
-        src_scale = _prep_scale(src_scale, self.n_src, "src_scale")
-        dst_scale = _prep_scale(dst_scale, self.n_dst, "dst_scale")
+        if X.dim() == 2 and X.shape[0] != self.n_src:
+            raise RuntimeError("X has %d rows, the graph has %d source nodes" % (X.shape[0], self.n_src))
+        args = (self.segptr, self.indices, vals, self.eid if keep is not None else None,
+                None if keep is None else _prep_keep(keep), X, None if src_scale is None else src_scale.reshape(-1),
+                None if dst_scale is None else dst_scale.reshape(-1), self.n_dst, self.n_slices)
         if out is None:
-            out = torch.empty((self.n_dst, F), dtype=torch.float32, device=dev)
-        elif out.dtype != torch.float32 or tuple(out.shape) != (self.n_dst, F) or not out.is_contiguous():
-            raise RuntimeError("out must be a contiguous float32 (%d, %d) tensor" % (self.n_dst, F))
-        with _guard(dev):
-            pbytes = self._pbytes.get(F)
-            if pbytes is None:
-                pbytes = self._pbytes[F] = int(_L.dgmi_spmm_sliced_planes_bytes(self.n_dst, self.n_slices, F))
-            planes = _scratch(pbytes, dev, "planes")
-            _lib.check(_L.dgmi_spmm_sliced_f32(self.segptr.data_ptr(), self.indices.data_ptr(), _ptr(vals),
-                                               p_eid, p_keep, n_keep, X.data_ptr(), ldx, _ptr(src_scale),
-                                               _ptr(dst_scale), out.data_ptr(), F, self.n_dst, self.n_src, F,
-                                               self.n_slices, planes.data_ptr(), pbytes, _stream(dev)),
-                       "dgmi_spmm_sliced_f32")
+            return _T.spmm_sliced_raw(*args)
+        _T.spmm_sliced_out(*args, out)
         return out
 
 
@@ -333,7 +216,14 @@ class SlicedCSR:
 # Measured on MI355X (tools/explore.py slicedcap, 10 M edges, F=128): sliced/planned time ratio
 # 1.0 at a 6 MB table, 1.9-2.4x at 13-51 MB, 1.2x at 102 MB, 1.0 at 205 MB; 1.55x at average
 # degree 100, 0.72x at 25 (a (row, slice) segment of 3 edges is all overhead).
-FORCE_KERNEL = {"planned": "planned", "sliced": "sliced"}.get(os.environ.get("DGMI_FORCE_KERNEL", ""))
+FORCE_KERNEL = {"planned": "planned", "sliced": "sliced", "dense": "dense"}.get(os.environ.get("DGMI_FORCE_KERNEL", ""))
+# Dense fast path (f3): the reference's encoder graph holds EVERY train pair, both
+# labels (data_loader.py:146-150,170), so a relation slice of a real dataset is a near-complete
+# bipartite block (lrssl: 464 897 of 519 603 cells) — "a dense-block tile actually materialises"
+# (north_star), and a plain fp32 GEMM through hipBLASLt beats any gather.  Taken when at least
+# DENSE_MIN_DENSITY of the cells hold an edge and the dense matrix stays small.
+DENSE_MIN_DENSITY = 0.25
+DENSE_MAX_CELLS = 1 << 24  # 64 MB of fp32
 SLICED_MIN_TABLE_BYTES = 10 << 20
 SLICED_MAX_TABLE_BYTES = 160 << 20
 SLICED_MIN_AVG_DEGREE = 64
@@ -555,23 +445,60 @@ class CSRGraph:
         dev = indptr.device
         if not X.is_cuda or X.device != dev:
             _require_device(indptr, X)
-        X, n_x, F, ldx = _prep_dense(X)
-        if n_x != n_cols:
-            raise RuntimeError("X has %d rows, the graph has %d source nodes" % (n_x, n_cols))
-        col_scale = _prep_scale(col_scale, n_cols, "src_scale")
-        row_scale = _prep_scale(row_scale, n_rows, "dst_scale")
-        if out is None:
-            out = torch.empty((n_rows, F), dtype=torch.float32, device=dev)
-        elif out.dtype != torch.float32 or tuple(out.shape) != (n_rows, F) or not out.is_contiguous():
-            raise RuntimeError("out must be a contiguous float32 (%d, %d) tensor" % (n_rows, F))
-        return _launch_spmm(dev, indptr, indices, vals, X, col_scale, row_scale, out, plan, n_rows, n_cols, F, ldx,
+        if X.dim() == 2 and X.shape[0] != n_cols:
+            raise RuntimeError("X has %d rows, the graph has %d source nodes" % (X.shape[0], n_cols))
+        return _launch_spmm(dev, indptr, indices, vals, X, None if col_scale is None else col_scale.reshape(-1),
+                            None if row_scale is None else row_scale.reshape(-1), out, plan, n_rows, n_cols, 0, 0,
                             eid if self._keep is not None else None, self._keep)
 
-    def spmm(self, X, src_scale=None, dst_scale=None, out=None):
-        """``diag(dst_scale) A diag(src_scale) X`` (no autograd).  Picks the XCD-local sliced
-        kernel when the feature table is a few L2s large and the graph is regular, else the
-        planned kernel."""
+    # -- dense fast path ----------------------------------------------------------------------------
+    def _use_dense(self) -> bool:
         S = self._S
+        cells = S.n_dst * S.n_src
+        if FORCE_KERNEL is not None:
+            return FORCE_KERNEL == "dense" and 0 < cells <= DENSE_MAX_CELLS
+        return 0 < cells <= DENSE_MAX_CELLS and self.nnz >= DENSE_MIN_DENSITY * cells
+
+    def _dense_matrix(self) -> torch.Tensor:
+        """A as a dense (n_dst, n_src) fp32 matrix of THIS view: entry = sum of the values (1 when
+        unweighted) of the surviving edges of that cell (duplicates add up, as in the sparse sums).
+        Built once per view — an edge-dropped view pays one mask pass, one scatter-add."""
+        A = self.__dict__.get("_dense")
+        if A is None:
+            S = self._S
+            w = self._coo_vals
+            if self._keep is not None:
+                m = keep_mask(self._keep, self.nnz)
+                w = m if w is None else w * m
+            if w is None:
+                w = torch.ones(self.nnz, dtype=torch.float32, device=S.dst.device)
+            A = torch.zeros((S.n_dst, S.n_src), dtype=torch.float32, device=S.dst.device)
+            A.index_put_((S.dst.long(), S.src.long()), w, accumulate=True)
+            self.__dict__["_dense"] = A
+        return A
+
+    def _dense_product(self, transposed: bool, X, col_scale, row_scale, out):
+        """``diag(row_scale) M diag(col_scale) X`` with M = A or A^T as one fp32 GEMM (hipBLASLt through
+        torch.mm).  Differs from the gather kernels only where X holds Inf / NaN in rows no edge
+        touches (0 * Inf): finite inputs agree to fp32 rounding."""
+        A = self._dense_matrix()
+        M = A.t() if transposed else A
+        if col_scale is not None:
+            X = X * col_scale.reshape(-1, 1)
+        Y = torch.mm(M, X, out=out) if out is not None else torch.mm(M, X)
+        if row_scale is not None:
+            Y.mul_(row_scale.reshape(-1, 1))
+        return Y
+
+    def spmm(self, X, src_scale=None, dst_scale=None, out=None):
+        """``diag(dst_scale) A diag(src_scale) X`` (no autograd).  Picks the dense GEMM for
+        near-complete blocks, the XCD-local sliced kernel when the feature table is a few L2s large
+        and the graph is regular, else the planned kernel."""
+        S = self._S
+        if X.dim() == 2 and self._use_dense():
+            if not X.is_cuda or X.device != S.indptr.device:
+                _require_device(S.indptr, X)
+            return self._dense_product(False, X, src_scale, dst_scale, out)
         if X.dim() == 2 and self._use_sliced(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
             if S.sliced is None:
                 S.sliced = SlicedCSR(S.dst, S.src, S.n_dst, S.n_src)
@@ -586,6 +513,10 @@ class CSRGraph:
     def spmm_t(self, dY, src_scale=None, dst_scale=None, out=None):
         """``diag(src_scale) A^T diag(dst_scale) dY`` — the backward of :meth:`spmm`."""
         S = self._S
+        if dY.dim() == 2 and self._use_dense():
+            if not dY.is_cuda or dY.device != S.indptr.device:
+                _require_device(S.indptr, dY)
+            return self._dense_product(True, dY, dst_scale, src_scale, out)
         indptr_t, indices_t, eid_t, plan_t = self._t_struct()
         if S.regular_t is None:  # one-time readback of the reversed graph's maximum degree
             max_deg = int((indptr_t[1:] - indptr_t[:-1]).max()) if self.nnz else 0
@@ -651,23 +582,13 @@ def _check_tables(A, B, n_src, n_dst):
 def gather_concat_raw(src, dst, A, B, out=None, n_src=None, n_dst=None) -> torch.Tensor:
     """``out[e] = cat(A[src[e]], B[dst[e]])`` through ``dgmi_gather_concat_f32`` (no autograd).
     ``n_src`` / ``n_dst``: the node counts ``src`` / ``dst`` ids were range-checked against."""
-    dev = _require_device(src, dst, A, B, out)
-    _check(src, torch.int32, "src", 1)
-    _check(dst, torch.int32, "dst", 1)
-    if src.shape != dst.shape:
-        raise RuntimeError("src/dst length mismatch")
-    A, n_a, Fa, lda = _prep_dense(A)
-    B, n_b, Fb, ldb = _prep_dense(B)
+    _require_device(src, dst, A, B, out)
     _check_tables(A, B, n_src, n_dst)
-    E = src.shape[0]
-    if out is None:
-        out = torch.empty((E, Fa + Fb), dtype=torch.float32, device=dev)
-    elif out.dtype != torch.float32 or tuple(out.shape) != (E, Fa + Fb) or not out.is_contiguous():
-        raise RuntimeError("out must be a contiguous float32 (%d, %d) tensor" % (E, Fa + Fb))
-    with _guard(dev):
-        _lib.check(_L.dgmi_gather_concat_f32(_ptr(src), _ptr(dst), E, _ptr(A), lda, Fa, _ptr(B), ldb, Fb,
-                                             _ptr(out), max(Fa + Fb, 1), _stream(dev)), "dgmi_gather_concat_f32")
-    return out
+    y = _T.gather_concat_raw(src, dst, A, B)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 class EdgePairs:
@@ -732,25 +653,13 @@ def gather_concat(pairs: EdgePairs, A: torch.Tensor, B: torch.Tensor) -> torch.T
 
 def gather_add_raw(src, dst, A, B, bias=None, out=None, n_src=None, n_dst=None) -> torch.Tensor:
     """``out[e] = A[src[e]] + B[dst[e]] (+ bias)`` through ``dgmi_gather_add_f32`` (no autograd)."""
-    dev = _require_device(src, dst, A, B, bias, out)
-    _check(src, torch.int32, "src", 1)
-    _check(dst, torch.int32, "dst", 1)
-    A, _, F, lda = _prep_dense(A)
-    B, _, Fb, ldb = _prep_dense(B)
+    _require_device(src, dst, A, B, bias, out)
     _check_tables(A, B, n_src, n_dst)
-    if F != Fb:
-        raise RuntimeError("A and B must have the same width, got %d and %d" % (F, Fb))
-    if bias is not None:
-        _check(bias, torch.float32, "bias", 1)
-        if bias.shape[0] != F:
-            raise RuntimeError("bias has %d entries, expected %d" % (bias.shape[0], F))
-    E = src.shape[0]
-    if out is None:
-        out = torch.empty((E, F), dtype=torch.float32, device=dev)
-    with _guard(dev):
-        _lib.check(_L.dgmi_gather_add_f32(_ptr(src), _ptr(dst), E, _ptr(A), lda, _ptr(B), ldb, _ptr(bias), F,
-                                          _ptr(out), max(F, 1), _stream(dev)), "dgmi_gather_add_f32")
-    return out
+    y = _T.gather_add_raw(src, dst, A, B, bias)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 class _GatherAdd(torch.autograd.Function):
@@ -785,23 +694,16 @@ def random_subset_select(E: int, keep: int, seed: int, device, e_offset: int = 0
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("dream_gnn_amd ops run on the MI355X only: got device %s" % device)
-    desc = torch.empty(8, dtype=torch.int32, device=device)
-    nbytes = int(_L.dgmi_random_subset_workspace_bytes())
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    with _guard(device):
-        _lib.check(_L.dgmi_random_subset_select(E, keep, seed & 0xFFFFFFFFFFFFFFFF, e_offset, _ptr(desc), _ptr(ws), nbytes,
-                                                _stream(device)), "dgmi_random_subset_select")
-    return desc
+    seed &= 0xFFFFFFFFFFFFFFFF
+    if seed >= 1 << 63:  # the op takes the 64 seed bits as a signed int
+        seed -= 1 << 64
+    return _T.random_subset_select(torch.empty(0, device=device), E, keep, seed, e_offset)
 
 
 def keep_mask(desc: torch.Tensor, E: int) -> torch.Tensor:
     """float 0/1 mask over edges [0, E) under the subset description(s) ``desc`` (``dgmi_keep_mask_f32``)."""
-    desc = _prep_keep(desc)
-    dev = _require_device(desc)
-    mask = torch.empty(E, dtype=torch.float32, device=dev)
-    with _guard(dev):
-        _lib.check(_L.dgmi_keep_mask_f32(_ptr(desc), int(desc.shape[0]), E, _ptr(mask), _stream(dev)), "dgmi_keep_mask_f32")
-    return mask
+    _require_device(desc)
+    return _T.keep_mask(_prep_keep(desc), E)
 
 
 def random_subset_mask(E: int, keep: int, seed: int, device) -> torch.Tensor:

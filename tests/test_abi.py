@@ -85,6 +85,25 @@ def test_argument_validation_returns_codes_without_a_gpu():
     assert L.dgmi_gather_f32(None, None, 0, None, None) == 0
 
 
+def test_torch_operator_library_is_registered():
+    """libdgmi_torch.so loads on the build box and registers the dreamgnn_mi ops of SURVEY §8(b)
+    for the HIP ("CUDA") dispatch key only — no CPU kernels exist."""
+    import torch
+
+    from dream_gnn_amd import _lib
+
+    assert os.path.exists(_lib.TORCH_LIB_PATH)
+    for name in ("csr_from_coo", "csr_sliced_from_coo", "plan_build", "spmm_csr", "spmm_csr_raw", "spmm_csr_out",
+                 "spmm_sliced_raw", "spmm_sliced_out", "gather_f32", "gather_concat_raw", "gather_add_raw",
+                 "random_subset_select", "keep_mask"):
+        assert hasattr(torch.ops.dreamgnn_mi, name), name
+    schema = torch.ops.dreamgnn_mi.spmm_csr.default._schema
+    assert [a.name for a in schema.arguments] == ["indptr", "indices", "vals", "X", "src_scale", "dst_scale"]
+    with pytest.raises(NotImplementedError):
+        torch.ops.dreamgnn_mi.spmm_csr(torch.zeros(2, dtype=torch.int32), torch.zeros(1, dtype=torch.int32), None,
+                                       torch.zeros(1, 4))
+
+
 def test_product_path_refuses_cpu_tensors():
     import torch
 
