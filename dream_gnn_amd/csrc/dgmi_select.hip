@@ -32,7 +32,19 @@ struct SelectState {
   uint32_t ties[kTieCap];
 };
 
-__global__ void init_state_kernel(SelectState* st, int64_t keep) {
+// Up to kMaxKeepSegs subsets are selected by ONE series of launches (a training step drops edges on
+// 4 relations and 4 similarity graphs at once — train.py:267 — and at dataset scale the launches,
+// not the hashing, are the cost): blockIdx.y says which subset a block works on.
+struct BatchParams {
+  int64_t E[kMaxKeepSegs];
+  int64_t keep[kMaxKeepSegs];
+  uint64_t seed[kMaxKeepSegs];
+  uint32_t e_offset[kMaxKeepSegs];
+};
+
+__global__ void init_state_kernel(SelectState* states, BatchParams p) {
+  SelectState* st = states + blockIdx.y;
+  const int64_t keep = p.keep[blockIdx.y];
   const int t = threadIdx.x;
   if (t == 0) {
     st->prefix = 0;
@@ -43,7 +55,10 @@ __global__ void init_state_kernel(SelectState* st, int64_t keep) {
   st->hist[t] = 0;
 }
 
-__global__ __launch_bounds__(kBlock) void hist_kernel(int64_t E, uint64_t seed, SelectState* st, int shift) {
+__global__ __launch_bounds__(kBlock) void hist_kernel(BatchParams p, SelectState* states, int shift) {
+  const int64_t E = p.E[blockIdx.y];
+  const uint64_t seed = p.seed[blockIdx.y];
+  SelectState* st = states + blockIdx.y;
   __shared__ uint32_t local[256];
   local[threadIdx.x] = 0;
   __syncthreads();
@@ -58,7 +73,8 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(int64_t E, uint64_t seed, 
 }
 
 // one thread: the bin holding the `remaining`-th smallest candidate becomes the next prefix byte
-__global__ void pick_kernel(SelectState* st, int shift) {
+__global__ void pick_kernel(SelectState* states, int shift) {
+  SelectState* st = states + blockIdx.y;
   if (threadIdx.x != 0) return;
   int64_t rem = st->remaining, before = 0;
   uint32_t b = 0;
@@ -73,7 +89,10 @@ __global__ void pick_kernel(SelectState* st, int shift) {
 }
 
 // lists the edges whose hash equals the threshold (~E / 2^32 of them)
-__global__ __launch_bounds__(kBlock) void ties_collect_kernel(int64_t E, uint64_t seed, SelectState* st) {
+__global__ __launch_bounds__(kBlock) void ties_collect_kernel(BatchParams p, SelectState* states) {
+  const int64_t E = p.E[blockIdx.y];
+  const uint64_t seed = p.seed[blockIdx.y];
+  SelectState* st = states + blockIdx.y;
   const uint32_t thr = st->prefix;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += stride) {
@@ -85,7 +104,12 @@ __global__ __launch_bounds__(kBlock) void ties_collect_kernel(int64_t E, uint64_
 }
 
 // one thread: among the ties keep the `remaining` smallest ids -> tie_cut; write the description
-__global__ void finalize_kernel(int64_t E, uint64_t seed, uint32_t e_offset, SelectState* st, KeepSeg* out) {
+__global__ void finalize_kernel(BatchParams p, SelectState* states, KeepSeg* descs) {
+  const int64_t E = p.E[blockIdx.y];
+  const uint64_t seed = p.seed[blockIdx.y];
+  const uint32_t e_offset = p.e_offset[blockIdx.y];
+  SelectState* st = states + blockIdx.y;
+  KeepSeg* out = descs + blockIdx.y;
   if (threadIdx.x != 0) return;
   const uint32_t thr = st->prefix;
   int32_t tie_cut = -1;
@@ -136,19 +160,35 @@ inline unsigned grid_for(int64_t n) {
 
 }  // namespace
 
-size_t random_subset_workspace_bytes() { return sizeof(SelectState) + sizeof(KeepSeg); }
+size_t random_subset_workspace_bytes() { return sizeof(SelectState) * kMaxKeepSegs + sizeof(KeepSeg); }
+
+hipError_t random_subset_select_batch(int n, const int64_t* E, const int64_t* keep, const uint64_t* seed,
+                                      const uint32_t* e_offset, void* descs, void* workspace, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  BatchParams p = {};
+  int64_t e_max = 0;
+  for (int i = 0; i < n; ++i) {
+    p.E[i] = E[i];
+    p.keep[i] = keep[i];
+    p.seed[i] = seed[i];
+    p.e_offset[i] = e_offset ? e_offset[i] : 0u;
+    if (E[i] > e_max) e_max = E[i];
+  }
+  SelectState* st = static_cast<SelectState*>(workspace);
+  const dim3 wide(grid_for(e_max), (unsigned)n), one(1, (unsigned)n);
+  hipLaunchKernelGGL(init_state_kernel, one, dim3(256), 0, s, st, p);
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hipLaunchKernelGGL(hist_kernel, wide, dim3(kBlock), 0, s, p, st, shift);
+    hipLaunchKernelGGL(pick_kernel, one, dim3(64), 0, s, st, shift);
+  }
+  hipLaunchKernelGGL(ties_collect_kernel, wide, dim3(kBlock), 0, s, p, st);
+  hipLaunchKernelGGL(finalize_kernel, one, dim3(64), 0, s, p, st, static_cast<KeepSeg*>(descs));
+  return hipGetLastError();
+}
 
 hipError_t random_subset_select(int64_t E, int64_t keep, uint64_t seed, uint32_t e_offset, void* seg_out,
                                 void* workspace, hipStream_t s) {
-  SelectState* st = static_cast<SelectState*>(workspace);
-  hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(256), 0, s, st, keep);
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    hipLaunchKernelGGL(hist_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, E, seed, st, shift);
-    hipLaunchKernelGGL(pick_kernel, dim3(1), dim3(64), 0, s, st, shift);
-  }
-  hipLaunchKernelGGL(ties_collect_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, E, seed, st);
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, s, E, seed, e_offset, st, static_cast<KeepSeg*>(seg_out));
-  return hipGetLastError();
+  return random_subset_select_batch(1, &E, &keep, &seed, &e_offset, seg_out, workspace, s);
 }
 
 hipError_t keep_mask_f32(const void* table, int n_seg, int64_t E, float* mask, hipStream_t s) {
@@ -161,7 +201,7 @@ hipError_t keep_mask_f32(const void* table, int n_seg, int64_t E, float* mask, h
 hipError_t random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask, void* workspace,
                                   hipStream_t s) {
   if (E == 0) return hipSuccess;
-  KeepSeg* seg = reinterpret_cast<KeepSeg*>(static_cast<char*>(workspace) + sizeof(SelectState));
+  KeepSeg* seg = reinterpret_cast<KeepSeg*>(static_cast<char*>(workspace) + sizeof(SelectState) * kMaxKeepSegs);
   hipError_t err = random_subset_select(E, keep, seed, 0u, seg, workspace, s);
   if (err != hipSuccess) return err;
   return keep_mask_f32(seg, 1, E, mask, s);

@@ -300,6 +300,30 @@ Tensor random_subset_select(const Tensor& like, int64_t E, int64_t keep, int64_t
   return desc;
 }
 
+// n <= 8 subsets with one series of launches; returns (n, 8) descriptions
+Tensor random_subset_select_batch(const Tensor& like, at::IntArrayRef E, at::IntArrayRef keep, at::IntArrayRef seed,
+                                  at::IntArrayRef e_offset) {
+  check_dev(like, "like");
+  const int64_t n = (int64_t)E.size();
+  TORCH_CHECK(n >= 1 && n <= 8 && (int64_t)keep.size() == n && (int64_t)seed.size() == n &&
+                  (e_offset.empty() || (int64_t)e_offset.size() == n),
+              "random_subset_select_batch: 1..8 subsets, E / keep / seed (/ e_offset) of equal length");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(like.device());
+  Tensor descs = at::empty({n, 8}, like.options().dtype(at::kInt));
+  const size_t nbytes = dgmi_random_subset_workspace_bytes();
+  Tensor ws = at::empty({(int64_t)nbytes}, like.options().dtype(at::kByte));
+  uint64_t seeds[8];
+  uint32_t offs[8];
+  for (int64_t i = 0; i < n; ++i) {
+    seeds[i] = (uint64_t)seed[i];
+    offs[i] = e_offset.empty() ? 0u : (uint32_t)e_offset[i];
+  }
+  check_status(dgmi_random_subset_select_batch((int32_t)n, E.data(), keep.data(), seeds, offs,
+                                               reinterpret_cast<uint32_t*>(descs.data_ptr<int32_t>()), ws.data_ptr(), nbytes,
+                                               stream_of(like)), "dgmi_random_subset_select_batch");
+  return descs;
+}
+
 Tensor keep_mask(const Tensor& keep, int64_t E) {
   check_dev(keep, "keep");
   TORCH_CHECK(keep.scalar_type() == at::kInt && keep.is_contiguous() && keep.dim() == 2 && keep.size(1) == 8 && keep.size(0) <= 8,
@@ -397,6 +421,7 @@ TORCH_LIBRARY(dreamgnn_mi, m) {
   m.def("gather_concat_raw(Tensor src, Tensor dst, Tensor A, Tensor B) -> Tensor");
   m.def("gather_add_raw(Tensor src, Tensor dst, Tensor A, Tensor B, Tensor? bias) -> Tensor");
   m.def("random_subset_select(Tensor like, int E, int keep, int seed, int e_offset=0) -> Tensor");
+  m.def("random_subset_select_batch(Tensor like, int[] E, int[] keep, int[] seed, int[] e_offset) -> Tensor");
   m.def("keep_mask(Tensor keep, int E) -> Tensor");
 }
 
@@ -414,6 +439,7 @@ TORCH_LIBRARY_IMPL(dreamgnn_mi, CUDA, m) {
   m.impl("gather_concat_raw", gather_concat_raw);
   m.impl("gather_add_raw", gather_add_raw);
   m.impl("random_subset_select", random_subset_select);
+  m.impl("random_subset_select_batch", random_subset_select_batch);
   m.impl("keep_mask", keep_mask);
 }
 

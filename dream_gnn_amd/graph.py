@@ -480,6 +480,7 @@ def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
     """
     out = HeteroGraph({}, {nt: graph.number_of_nodes(nt) for nt in graph.ntypes})
     nested = False
+    pending = []  # relations whose subset is an on-the-fly description: selected together below
     for can in graph.canonical_etypes:
         rel = graph[can]
         st, _, dt = can
@@ -497,8 +498,19 @@ def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
             out._rels[can] = child
             continue
         keep = max(1, int(E * (1 - dropout_rate)))
-        keep_idx, desc = _select_kept(E, keep, rel.device, generator, selection)
-        out._rels[can] = DroppedRelation(rel, keep, out._ndata[st], out._ndata[dt], keep_idx=keep_idx, desc=desc)
+        sel = selection or ("select" if rel.device.type == "cuda" else "randperm")
+        seed = _draw_seed(generator) if sel == "select" else None  # one draw per edge type, in canonical order
+        if seed is not None:
+            out._rels[can] = None  # keeps the canonical position
+            pending.append((can, rel, keep, seed))
+        else:
+            keep_idx = torch.randperm(E, device=rel.device, generator=generator)[:keep]
+            out._rels[can] = DroppedRelation(rel, keep, out._ndata[st], out._ndata[dt], keep_idx=keep_idx)
+    if pending:
+        descs = ops.random_subset_select_batch([r.number_of_edges() for _, r, _, _ in pending], [k for _, _, k, _ in pending],
+                                               [s for _, _, _, s in pending], pending[0][1].device)
+        for i, (can, rel, keep, _) in enumerate(pending):
+            out._rels[can] = DroppedRelation(rel, keep, out._ndata[can[0]], out._ndata[can[2]], desc=descs[i])
     if not nested:
         out.__dict__["_dropout_parent"] = graph
     for nt in graph.ntypes:
@@ -538,6 +550,23 @@ def random_edge_dropout_sparse(adj, dropout_rate: float = 0.1, generator: Option
     out._dgmi_parent = adj
     out._dgmi_keep_idx = perm
     return out
+
+
+def random_edge_dropout_sparse_views(adjs, dropout_rate: float = 0.1, generator: Optional[torch.Generator] = None):
+    """``random_edge_dropout_sparse(..., as_view=True)`` for several adjacencies at once (the four
+    similarity / feature graphs of a training step, augmentation.py:448-458): one seed draw per graph,
+    in the given order, then ONE batched subset selection.  Returns masked ``CSRGraph`` views."""
+    from .layers import adjacency_csr  # local import: layers imports this module
+
+    bases = [adjacency_csr(a) for a in adjs]
+    if not bases:
+        return []
+    if bases[0].device.type != "cuda" or (generator is not None and generator.device.type != "cpu"):
+        return [random_edge_dropout_sparse(a, dropout_rate, generator, as_view=True) for a in adjs]
+    keeps = [max(1, int(b.nnz * (1 - dropout_rate))) for b in bases]
+    seeds = [_draw_seed(generator) for _ in bases]
+    descs = ops.random_subset_select_batch([b.nnz for b in bases], keeps, seeds, bases[0].device)
+    return [b.dropped(descs[i]) for i, b in enumerate(bases)]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -29,11 +29,12 @@ def augment(batch: Dict, edge_dropout_rate: float = 0.1, feature_noise_scale: fl
     The decoder graph is not augmented (train.py:270)."""
     out = dict(batch)
     out["enc_graph"] = G.random_edge_dropout(batch["enc_graph"], edge_dropout_rate, generator)
-    for k in ("drug_graph", "disease_graph", "drug_feature_graph", "disease_feature_graph"):
-        if batch.get(k) is not None:
-            # a masked view of the cached CSR (GraphConvolution accepts it); the reference's sparse
-            # tensor is available with as_view=False
-            out[k] = G.random_edge_dropout_sparse(batch[k], edge_dropout_rate, generator, as_view=True)
+    # masked views of the cached CSRs (GraphConvolution accepts them; the reference's sparse tensors are
+    # available from G.random_edge_dropout_sparse), all four subsets selected by one series of launches
+    keys = [k for k in ("drug_graph", "disease_graph", "drug_feature_graph", "disease_feature_graph")
+            if batch.get(k) is not None]
+    for k, view in zip(keys, G.random_edge_dropout_sparse_views([batch[k] for k in keys], edge_dropout_rate, generator)):
+        out[k] = view
     for k, scale in (("drug_feat", feature_noise_scale), ("disease_feat", feature_noise_scale),
                      ("drug_sim_feat", sim_noise_scale), ("disease_sim_feat", sim_noise_scale)):
         if batch.get(k) is not None:

@@ -694,10 +694,29 @@ def random_subset_select(E: int, keep: int, seed: int, device, e_offset: int = 0
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("dream_gnn_amd ops run on the MI355X only: got device %s" % device)
+    return _T.random_subset_select(torch.empty(0, device=device), E, keep, _signed64(seed), e_offset)
+
+
+def _signed64(seed: int) -> int:
     seed &= 0xFFFFFFFFFFFFFFFF
-    if seed >= 1 << 63:  # the op takes the 64 seed bits as a signed int
-        seed -= 1 << 64
-    return _T.random_subset_select(torch.empty(0, device=device), E, keep, seed, e_offset)
+    return seed - (1 << 64) if seed >= 1 << 63 else seed
+
+
+def random_subset_select_batch(Es, keeps, seeds, device, e_offsets=None) -> torch.Tensor:
+    """``random_subset_select`` for several edge lists at once: ``(n, 8)`` descriptions from ONE series
+    of launches per 8 lists (``dgmi_random_subset_select_batch``) — the training step drops edges on
+    4 relations and 4 similarity graphs together (train.py:267), and at dataset scale the launches
+    are the cost of the selection."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("dream_gnn_amd ops run on the MI355X only: got device %s" % device)
+    n = len(Es)
+    offs = [0] * n if e_offsets is None else list(e_offsets)
+    like = torch.empty(0, device=device)
+    parts = [_T.random_subset_select_batch(like, list(Es[i:i + 8]), list(keeps[i:i + 8]),
+                                           [_signed64(s) for s in seeds[i:i + 8]], offs[i:i + 8])
+             for i in range(0, n, 8)]
+    return parts[0] if len(parts) == 1 else torch.cat(parts)
 
 
 def keep_mask(desc: torch.Tensor, E: int) -> torch.Tensor:

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 9
+#define DGMI_ABI_VERSION 10
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -240,6 +240,10 @@ DGMI_API int dgmi_gather_add_f32(const int32_t* src, const int32_t* dst, int64_t
  *                               threshold hash, tie cut, 0, 0}; edge e_offset + i is kept iff
  *                               hash32(seed, i) < thr || (hash32(seed, i) == thr && i <= tie cut).
  *                               This is what the SpMM entry points take as `keep`.
+ *   dgmi_random_subset_select_batch  the same for n <= 8 edge lists with ONE series of launches (the
+ *                               E / keep / seed / e_offset arrays are HOST arrays of length n, e_offset
+ *                               may be NULL; descs: n x 8 words on the device): a training step selects
+ *                               8 subsets at once (train.py:267) and at dataset scale launches dominate.
  *   dgmi_keep_mask_f32          mask[e] = 1.0f / 0.0f for e in [0, E) under n_keep descriptions.
  *   dgmi_random_subset_mask_f32 both in one call (e_offset = 0).
  */
@@ -247,6 +251,10 @@ DGMI_API size_t dgmi_random_subset_workspace_bytes(void);
 DGMI_API int dgmi_random_subset_select(int64_t E, int64_t keep, uint64_t seed, uint32_t e_offset,
                                        uint32_t* desc, void* workspace, size_t workspace_bytes,
                                        dgmi_stream_t stream);
+DGMI_API int dgmi_random_subset_select_batch(int32_t n, const int64_t* E /* host */, const int64_t* keep /* host */,
+                                             const uint64_t* seed /* host */, const uint32_t* e_offset /* host */,
+                                             uint32_t* descs, void* workspace, size_t workspace_bytes,
+                                             dgmi_stream_t stream);
 DGMI_API int dgmi_keep_mask_f32(const uint32_t* keep, int32_t n_keep, int64_t E, float* mask,
                                 dgmi_stream_t stream);
 DGMI_API int dgmi_random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask,

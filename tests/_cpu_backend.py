@@ -66,6 +66,11 @@ def random_subset_select(E, keep, seed, device, e_offset=0):
     return torch.from_numpy(O.random_subset_select(E, keep, seed, e_offset).copy())
 
 
+def random_subset_select_batch(Es, keeps, seeds, device, e_offsets=None):
+    offs = [0] * len(Es) if e_offsets is None else list(e_offsets)
+    return torch.stack([random_subset_select(E, k, s, device, o) for E, k, s, o in zip(Es, keeps, seeds, offs)])
+
+
 def keep_mask(desc, E):
     return torch.from_numpy(O.keep_mask(desc.numpy(), E))
 
@@ -83,7 +88,7 @@ def patched():
     from dream_gnn_amd import ops
 
     names = ("csr_from_coo", "gather_f32", "spmm_csr_raw", "_launch_spmm", "_require_device", "build_plan", "FORCE_KERNEL",
-             "gather_concat_raw", "gather_add_raw", "random_subset_mask", "random_subset_select", "keep_mask")
+             "gather_concat_raw", "gather_add_raw", "random_subset_mask", "random_subset_select", "random_subset_select_batch", "keep_mask")
     saved = {k: getattr(ops, k) for k in names}
     ops.csr_from_coo, ops.gather_f32, ops.spmm_csr_raw = csr_from_coo, gather_f32, spmm_csr_raw
     ops._launch_spmm = _launch_spmm
@@ -91,6 +96,7 @@ def patched():
     ops.gather_add_raw = gather_add_raw
     ops.random_subset_mask = random_subset_mask
     ops.random_subset_select = random_subset_select
+    ops.random_subset_select_batch = random_subset_select_batch
     ops.keep_mask = keep_mask
     ops._require_device = lambda *ts: next((t.device for t in ts if t is not None), None)
     ops.build_plan = lambda indptr, nnz, chunk=None: None  # launch plans are a device-side concern

@@ -513,3 +513,20 @@ def test_edge_dropout_on_the_fly_every_kernel(oracle, dev, F, weighted):
     x = t(X).requires_grad_(True)
     ops.spmm_csr(view, x, ssd, dsd).backward(t(W))
     assert np.all(np.abs(x.grad.cpu().numpy() - ref_t) <= RTOL * bound_t + 1e-30)
+
+
+def test_batched_subset_selection_equals_single_calls(oracle, dev):
+    """8 subsets from one series of launches (dgmi_random_subset_select_batch) == 8 single selections
+    == the oracle, with different sizes, offsets and an empty keep among them."""
+    from dream_gnn_amd import ops
+
+    Es = [1, 7, 1000, 465_000, 2_746, 100_003, 50, 6_800, 33, 12]  # 10 lists: two batches
+    keeps = [1, 3, 900, 418_500, 2_471, 0, 50, 6_120, 1, 11]
+    seeds = [0, 1, 2 ** 64 - 1, 12345678901234567, 5, 6, 7, 2 ** 63, 9, 10]
+    offs = [0, 5, 0, 1000, 0, 7, 0, 0, 3, 0]
+    d = ops.random_subset_select_batch(Es, keeps, seeds, dev, offs)
+    assert tuple(d.shape) == (10, 8)
+    for i in range(10):
+        want = oracle.random_subset_select(Es[i], keeps[i], seeds[i], offs[i])
+        assert np.array_equal(d[i].cpu().numpy(), want), i
+        assert torch.equal(d[i], ops.random_subset_select(Es[i], keeps[i], seeds[i], dev, e_offset=offs[i])), i
