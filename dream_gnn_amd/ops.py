@@ -224,9 +224,14 @@ FORCE_KERNEL = {"planned": "planned", "sliced": "sliced", "dense": "dense"}.get(
 # DENSE_MIN_DENSITY of the cells hold an edge and the dense matrix stays small.
 DENSE_MIN_DENSITY = 0.25
 DENSE_MAX_CELLS = 1 << 24  # 64 MB of fp32
+# Round 2 (tools/cfg5_forms_probe.py): on the node-scaled config-5 shards the sliced pair still wins at
+# 204 MB / degree 100 (0.737 vs 0.784 ms) and 409 MB / degree 200 (0.739 vs 0.820 ms), and loses badly
+# once a row has few edges per slice (degree 25: 0.924 vs 0.677 ms; 12.5: 1.754 vs 0.643 ms).
 SLICED_MIN_TABLE_BYTES = 10 << 20
 SLICED_MAX_TABLE_BYTES = 160 << 20
 SLICED_MIN_AVG_DEGREE = 64
+SLICED_HUGE_TABLE_BYTES = 448 << 20   # tables between MAX and HUGE: only with SLICED_HUGE_MIN_AVG_DEGREE
+SLICED_HUGE_MIN_AVG_DEGREE = 96
 
 
 class _Structure:
@@ -415,8 +420,11 @@ class CSRGraph:
         if FORCE_KERNEL is not None:  # debugging / A-B aid: DGMI_FORCE_KERNEL=planned|sliced
             return FORCE_KERNEL == "sliced" and F % 4 == 0 and n_rows * SlicedCSR.N_SLICES < 2 ** 31 - 1
         table = n_cols * F * 4
-        return (bool(regular) and F % 4 == 0 and SLICED_MIN_TABLE_BYTES <= table <= SLICED_MAX_TABLE_BYTES
-                and self.nnz >= SLICED_MIN_AVG_DEGREE * n_rows and n_rows * SlicedCSR.N_SLICES < 2 ** 31 - 1)
+        if not (bool(regular) and F % 4 == 0 and n_rows * SlicedCSR.N_SLICES < 2 ** 31 - 1):
+            return False
+        if SLICED_MIN_TABLE_BYTES <= table <= SLICED_MAX_TABLE_BYTES:
+            return self.nnz >= SLICED_MIN_AVG_DEGREE * n_rows
+        return SLICED_MAX_TABLE_BYTES < table <= SLICED_HUGE_TABLE_BYTES and self.nnz >= SLICED_HUGE_MIN_AVG_DEGREE * n_rows
 
     def _use_split(self, F: int, n_rows: int, n_cols: int, regular) -> bool:
         """Long-row graphs (power laws): same table / degree criteria, rows cut into virtual rows.
