@@ -14,11 +14,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgmi.so")
 TORCH_LIB_PATH = os.path.join(_HERE, "libdgmi_torch.so")  # the dreamgnn_mi::* dispatcher ops over the C ABI
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # name -> (restype, argtypes); mirrors include/dgmi.h one to one.
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
+_EPI = [ctypes.c_int32, ctypes.c_float, _vp, _i64, ctypes.c_float]  # act, act_slope, out_mask, ld_mask, out_mask_scale
 
 
 SIGNATURES = {
@@ -28,15 +29,16 @@ SIGNATURES = {
     "dgmi_csr_from_coo_i32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp,
                                              ctypes.POINTER(ctypes.c_size_t), _vp]),
     "dgmi_spmm_csr_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp, _vp, _vp, _i64, _i64,
-                                         _i64, _i64, _vp]),
+                                         _i64, _i64] + _EPI + [_vp]),
     "dgmi_gather_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "dgmi_gather_concat_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "dgmi_csr_sliced_from_coo_i32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, ctypes.c_int32, _vp, _vp, _vp, _vp,
                                                     ctypes.POINTER(ctypes.c_size_t), _vp]),
     "dgmi_spmm_sliced_planes_bytes": (ctypes.c_size_t, [_i64, ctypes.c_int32, _i64]),
     "dgmi_spmm_sliced_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp, _vp, _vp, _i64, _i64,
-                                            _i64, _i64, ctypes.c_int32, _vp, ctypes.c_size_t, _vp]),
+                                            _i64, _i64, ctypes.c_int32, _vp, ctypes.c_size_t] + _EPI + [_vp]),
     "dgmi_probe_row_gather_f32": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int32, _vp, _vp]),
+    "dgmi_epilogue_backward_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, ctypes.c_int32, ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "dgmi_gather_add_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "dgmi_random_subset_workspace_bytes": (ctypes.c_size_t, []),
     "dgmi_random_subset_mask_f32": (ctypes.c_int, [_i64, _i64, ctypes.c_uint64, _vp, _vp, ctypes.c_size_t, _vp]),
@@ -46,7 +48,8 @@ SIGNATURES = {
     "dgmi_spmm_plan_build": (ctypes.c_int, [_vp, _i64, _i64, ctypes.c_int32, _vp, ctypes.c_size_t, _vp,
                                             ctypes.POINTER(ctypes.c_size_t), _vp]),
     "dgmi_spmm_csr_planned_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp, _vp, _vp, _i64,
-                                                 _i64, _i64, _i64, _i64, ctypes.c_int32, _vp, _vp, ctypes.c_size_t, _vp]),
+                                                 _i64, _i64, _i64, _i64, ctypes.c_int32, _vp, _vp, ctypes.c_size_t] + _EPI
+                                  + [_vp]),
     "dgmi_random_subset_select": (ctypes.c_int, [_i64, _i64, ctypes.c_uint64, ctypes.c_uint32, _vp, _vp, ctypes.c_size_t,
                                                  _vp]),
     "dgmi_random_subset_select_batch": (ctypes.c_int, [ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),

@@ -66,6 +66,10 @@ DGMI_API int dgmi_csr_from_coo_i32(const int32_t* row, const int32_t* col, int64
                                          workspace_bytes, as_stream(stream)));
 }
 
+static bool epilogue_ok(int32_t act, const float* out_mask, int64_t ld_mask, int64_t F) {
+  return (act == 0 || act == 1) && (out_mask == nullptr || ld_mask >= F);
+}
+
 static bool keep_args_ok(const int32_t* eid, const uint32_t* keep, int32_t n_keep) {
   if (n_keep < 0 || n_keep > dgmi::kMaxKeepSegs) return false;
   return n_keep == 0 || (eid != nullptr && keep != nullptr);
@@ -75,8 +79,10 @@ DGMI_API int dgmi_spmm_csr_f32(const int32_t* indptr, const int32_t* indices, co
                       const int32_t* eid, const uint32_t* keep, int32_t n_keep,
                       const float* X, int64_t ldx, const float* src_scale,
                       const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
-                      int64_t n_src, int64_t F, dgmi_stream_t stream) {
-  if (n_dst < 0 || n_src < 0 || F < 0 || !keep_args_ok(eid, keep, n_keep)) return DGMI_ERR_INVALID_ARG;
+                      int64_t n_src, int64_t F, int32_t act, float act_slope, const float* out_mask,
+                      int64_t ld_mask, float out_mask_scale, dgmi_stream_t stream) {
+  if (n_dst < 0 || n_src < 0 || F < 0 || !keep_args_ok(eid, keep, n_keep) || !epilogue_ok(act, out_mask, ld_mask, F))
+    return DGMI_ERR_INVALID_ARG;
   if (n_dst >= INT32_MAX || n_src >= INT32_MAX || F > INT32_MAX) return DGMI_ERR_TOO_LARGE;
   if (n_dst == 0 || F == 0) return DGMI_OK;
   if (indptr == nullptr || Y == nullptr) return DGMI_ERR_INVALID_ARG;
@@ -86,7 +92,7 @@ DGMI_API int dgmi_spmm_csr_f32(const int32_t* indptr, const int32_t* indices, co
   if (X == nullptr && n_src > 0) return DGMI_ERR_INVALID_ARG;
   if (static_cast<const void*>(X) == static_cast<const void*>(Y)) return DGMI_ERR_INVALID_ARG;
   dgmi::SpmmArgs a{indptr, indices, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F,
-                   nullptr, 0, 0, nullptr, 0, eid, keep, n_keep};
+                   nullptr, 0, 0, nullptr, 0, eid, keep, n_keep, {act, act_slope, out_mask, ld_mask, out_mask_scale}};
   return from_hip(dgmi::spmm_csr_f32(a, as_stream(stream)));
 }
 
@@ -142,8 +148,11 @@ DGMI_API int dgmi_spmm_csr_planned_f32(const int32_t* indptr, const int32_t* ind
                                        const float* src_scale, const float* dst_scale, float* Y,
                                        int64_t ldy, int64_t n_dst, int64_t n_src, int64_t F,
                                        int64_t nnz, int32_t chunk, const void* plan, void* partials,
-                                       size_t partials_bytes, dgmi_stream_t stream) {
-  if (n_dst < 0 || n_src < 0 || F < 0 || nnz < 0 || !chunk_ok(chunk) || !keep_args_ok(eid, keep, n_keep))
+                                       size_t partials_bytes, int32_t act, float act_slope,
+                                       const float* out_mask, int64_t ld_mask, float out_mask_scale,
+                                       dgmi_stream_t stream) {
+  if (n_dst < 0 || n_src < 0 || F < 0 || nnz < 0 || !chunk_ok(chunk) || !keep_args_ok(eid, keep, n_keep) ||
+      !epilogue_ok(act, out_mask, ld_mask, F))
     return DGMI_ERR_INVALID_ARG;
   if (n_dst >= INT32_MAX || n_src >= INT32_MAX || F > INT32_MAX || nnz > INT32_MAX)
     return DGMI_ERR_TOO_LARGE;
@@ -156,7 +165,7 @@ DGMI_API int dgmi_spmm_csr_planned_f32(const int32_t* indptr, const int32_t* ind
   if (partials_bytes < dgmi_spmm_partials_bytes(nnz, chunk, F)) return DGMI_ERR_WORKSPACE;
   dgmi::SpmmArgs a{indptr, indices, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F,
                    static_cast<const int32_t*>(plan), nnz, chunk, static_cast<float*>(partials),
-                   (F + 3) / 4 * 4, eid, keep, n_keep};
+                   (F + 3) / 4 * 4, eid, keep, n_keep, {act, act_slope, out_mask, ld_mask, out_mask_scale}};
   return from_hip(dgmi::spmm_csr_f32(a, as_stream(stream)));
 }
 
@@ -214,9 +223,12 @@ DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices,
                                   const float* X, int64_t ldx, const float* src_scale,
                                   const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
                                   int64_t n_src, int64_t F, int32_t n_slices, void* planes,
-                                  size_t planes_bytes, dgmi_stream_t stream) {
-  if (n_dst < 0 || n_src < 0 || F < 0 || n_slices < 1 || n_slices > 64 || !keep_args_ok(eid, keep, n_keep))
+                                  size_t planes_bytes, int32_t act, float act_slope, const float* out_mask,
+                                  int64_t ld_mask, float out_mask_scale, dgmi_stream_t stream) {
+  if (n_dst < 0 || n_src < 0 || F < 0 || n_slices < 1 || n_slices > 64 || !keep_args_ok(eid, keep, n_keep) ||
+      !epilogue_ok(act, out_mask, ld_mask, F))
     return DGMI_ERR_INVALID_ARG;
+  if (out_mask != nullptr && (ld_mask % 4 != 0 || (reinterpret_cast<uintptr_t>(out_mask) & 15))) return DGMI_ERR_INVALID_ARG;
   if (n_dst >= INT32_MAX || n_src >= INT32_MAX || F > INT32_MAX) return DGMI_ERR_TOO_LARGE;
   if (n_dst == 0 || F == 0) return DGMI_OK;
   if (segptr == nullptr || Y == nullptr || planes == nullptr) return DGMI_ERR_INVALID_ARG;
@@ -228,7 +240,8 @@ DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices,
   if (static_cast<const void*>(X) == static_cast<const void*>(Y)) return DGMI_ERR_INVALID_ARG;
   if (planes_bytes < dgmi_spmm_sliced_planes_bytes(n_dst, n_slices, F)) return DGMI_ERR_WORKSPACE;
   dgmi::SlicedArgs a{segptr, indices, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F, n_slices,
-                     static_cast<float*>(planes), F, sliced_chunk_rows(n_dst, n_slices, F), eid, keep, n_keep};
+                     static_cast<float*>(planes), F, sliced_chunk_rows(n_dst, n_slices, F), eid, keep, n_keep,
+                     {act, act_slope, out_mask, ld_mask, out_mask_scale}};
   return from_hip(dgmi::spmm_sliced_f32(a, as_stream(stream)));
 }
 
@@ -254,6 +267,14 @@ DGMI_API int dgmi_gather_add_f32(const int32_t* src, const int32_t* dst, int64_t
     return DGMI_ERR_INVALID_ARG;
   if (lda < F || ldb < F || ldo < F) return DGMI_ERR_INVALID_ARG;
   return from_hip(dgmi::gather_add_f32(src, dst, E, A, lda, B, ldb, bias, F, out, ldo, as_stream(stream)));
+}
+
+DGMI_API int dgmi_epilogue_backward_f32(const float* dY, const float* Y, const float* mask, int64_t n, int32_t act,
+                                        float act_slope, float mask_scale, float* out, dgmi_stream_t stream) {
+  if (n < 0 || (act != 0 && act != 1)) return DGMI_ERR_INVALID_ARG;
+  if (n == 0) return DGMI_OK;
+  if (dY == nullptr || out == nullptr || (act == 1 && Y == nullptr)) return DGMI_ERR_INVALID_ARG;
+  return from_hip(dgmi::epilogue_backward_f32(dY, Y, mask, n, act, act_slope, mask_scale, out, as_stream(stream)));
 }
 
 DGMI_API size_t dgmi_random_subset_workspace_bytes(void) { return dgmi::random_subset_workspace_bytes(); }

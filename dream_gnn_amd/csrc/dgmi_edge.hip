@@ -174,4 +174,31 @@ hipError_t gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, con
   return hipGetLastError();
 }
 
+// Backward of the fused output epilogue (dgmi_kernels.h Epilogue):  g = dY * act'(Y) * mask * mask_scale.
+// Y is the epilogue's OUTPUT: where the mask kept an element its sign is the pre-activation's sign (leaky
+// slope > 0; for relu a zero output has zero derivative either way), where the mask dropped it the factor is 0.
+namespace {
+__global__ __launch_bounds__(256) void epilogue_backward_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                                const float* __restrict__ mask, int64_t n, int act,
+                                                                float slope, float mask_scale, float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float g = dY[i];
+    if (act == 1) g = Y[i] > 0.f ? g : g * slope;
+    if (mask != nullptr) g *= mask[i] * mask_scale;
+    out[i] = g;
+  }
+}
+}  // namespace
+
+hipError_t epilogue_backward_f32(const float* dY, const float* Y, const float* mask, int64_t n, int act, float slope,
+                                 float mask_scale, float* out, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(epilogue_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dY, Y, mask, n, act, slope,
+                     mask_scale, out);
+  return hipGetLastError();
+}
+
 }  // namespace dgmi

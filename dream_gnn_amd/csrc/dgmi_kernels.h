@@ -52,6 +52,16 @@ inline int pick_lpr(int64_t F) {
   return best;
 }
 
+// Output epilogue fused into the kernel that writes Y (f3: GCMCLayer's `dropout(agg_act(...))`,
+// reference layers.py:134-138):  Y = mask * mask_scale * act(dst_scale * sum)
+struct Epilogue {
+  int act;            // 0: none; 1: leaky-relu with `slope` (slope 0 = relu), as torch: v > 0 ? v : v * slope
+  float slope;
+  const float* mask;  // nullable: (n_dst, F) keep mask with leading dimension ldm (a multiple of 4 on the 16-B paths)
+  int64_t ldm;
+  float mask_scale;   // 1 / (1 - p)
+};
+
 struct SpmmArgs {
   const int32_t* indptr;
   const int32_t* indices;
@@ -76,6 +86,7 @@ struct SpmmArgs {
   const int32_t* eid;
   const void* keep;
   int n_keep;
+  Epilogue ep;
 };
 
 // Y = diag(dst_scale) A diag(src_scale) X   (dgmi_spmm.hip)
@@ -115,6 +126,7 @@ struct SlicedArgs {
   const int32_t* eid;      // edge dropout on the fly, as SpmmArgs
   const void* keep;
   int n_keep;
+  Epilogue ep;
 };
 hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s);
 
@@ -127,6 +139,10 @@ hipError_t gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, 
 hipError_t gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A, int64_t lda,
                           const float* B, int64_t ldb, const float* bias, int64_t F, float* out,
                           int64_t ldo, hipStream_t s);
+
+// g = dY * act'(Y) * mask * mask_scale over n contiguous elements: backward of the fused epilogue (dgmi_edge.hip)
+hipError_t epilogue_backward_f32(const float* dY, const float* Y, const float* mask, int64_t n, int act, float slope,
+                                 float mask_scale, float* out, hipStream_t s);
 
 // mask[e] = 1 for a uniformly random subset of exactly `keep` of the E edges (dgmi_select.hip)
 size_t random_subset_workspace_bytes();

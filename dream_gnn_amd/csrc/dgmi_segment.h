@@ -5,9 +5,34 @@
 #include <stdint.h>
 
 #include "dgmi_keep.h"
+#include "dgmi_kernels.h"
 
 namespace dgmi {
 namespace {
+
+// Epilogue of the kernel that writes Y: activation, then the (dropout) keep mask.
+__device__ __forceinline__ float epilogue1(const Epilogue& ep, float v, int64_t row, int col) {
+  if (ep.act == 1) v = v > 0.f ? v : v * ep.slope;
+  if (ep.mask != nullptr) v *= ep.mask[row * ep.ldm + col] * ep.mask_scale;
+  return v;
+}
+
+__device__ __forceinline__ float4 epilogue4(const Epilogue& ep, float4 v, int64_t row, int col) {
+  if (ep.act == 1) {
+    v.x = v.x > 0.f ? v.x : v.x * ep.slope;
+    v.y = v.y > 0.f ? v.y : v.y * ep.slope;
+    v.z = v.z > 0.f ? v.z : v.z * ep.slope;
+    v.w = v.w > 0.f ? v.w : v.w * ep.slope;
+  }
+  if (ep.mask != nullptr) {
+    const float4 m = *reinterpret_cast<const float4*>(ep.mask + row * ep.ldm + col);
+    v.x *= m.x * ep.mask_scale;
+    v.y *= m.y * ep.mask_scale;
+    v.z *= m.z * ep.mask_scale;
+    v.w *= m.w * ep.mask_scale;
+  }
+  return v;
+}
 
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;

@@ -175,7 +175,7 @@ template <bool HAS_DS, int S>
 __global__ __launch_bounds__(256) void reduce_planes_kernel(const float* __restrict__ planes, int64_t ldp,
                                                             int64_t rows, int F4, int n_slices,
                                                             const float* __restrict__ dst_scale,
-                                                            float* __restrict__ Y, int64_t ldy) {
+                                                            float* __restrict__ Y, int64_t ldy, Epilogue ep) {
   const int64_t total = rows * F4;
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t plane_stride = rows * ldp;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void reduce_planes_kernel(const float* __restr
       acc.z *= d;
       acc.w *= d;
     }
-    *reinterpret_cast<float4*>(Y + yoff) = acc;
+    *reinterpret_cast<float4*>(Y + yoff) = epilogue4(ep, acc, row, (int)(yoff - row * ldy));
   }
 }
 
@@ -276,9 +276,11 @@ hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s) {
     if (blocks > 8192) blocks = 8192;
     const float* ds = a.dst_scale ? a.dst_scale + r0 : nullptr;
     float* y = a.Y + r0 * a.ldy;
+    Epilogue ep = a.ep;  // rows of this chunk start at r0
+    if (ep.mask != nullptr) ep.mask += r0 * ep.ldm;
 #define DGMI_REDUCE(D, S)                                                                               \
   hipLaunchKernelGGL((reduce_planes_kernel<D, S>), dim3((unsigned)blocks), dim3(256), 0, s, a.planes, a.ldp, \
-                     r1 - r0, F4, (int)a.n_slices, ds, y, a.ldy)
+                     r1 - r0, F4, (int)a.n_slices, ds, y, a.ldy, ep)
     if (a.n_slices == 8) {
       if (ds) DGMI_REDUCE(true, 8); else DGMI_REDUCE(false, 8);
     } else {

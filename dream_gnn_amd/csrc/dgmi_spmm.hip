@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_csr_vec4_kernel(
     const float* __restrict__ src_scale, const float* __restrict__ dst_scale,
     float* __restrict__ Y, int64_t ldy, int64_t n_dst, int F,
     const int32_t* __restrict__ plan, float* __restrict__ P, int64_t ldp,
-    const int32_t* __restrict__ eid, const KeepSeg* __restrict__ keep, int n_keep) {
+    const int32_t* __restrict__ eid, const KeepSeg* __restrict__ keep, int n_keep, Epilogue ep) {
   Segment sg;
   if (!fetch_segment<PLANNED>(indptr, plan, n_dst, sg)) return;  // wave-uniform
   const int lane = threadIdx.x & (kWave - 1);
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_csr_vec4_kernel(
         acc.z *= d;
         acc.w *= d;
       }
-      *reinterpret_cast<float4*>(Y + sg.row * ldy + col) = acc;
+      *reinterpret_cast<float4*>(Y + sg.row * ldy + col) = epilogue4(ep, acc, sg.row, col);
     }
   }
 }
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_csr_dword_kernel(
     const float* __restrict__ src_scale, const float* __restrict__ dst_scale,
     float* __restrict__ Y, int64_t ldy, int64_t n_dst, int F,
     const int32_t* __restrict__ plan, float* __restrict__ P, int64_t ldp,
-    const int32_t* __restrict__ eid, const KeepSeg* __restrict__ keep, int n_keep) {
+    const int32_t* __restrict__ eid, const KeepSeg* __restrict__ keep, int n_keep, Epilogue ep) {
   Segment sg;
   if (!fetch_segment<PLANNED>(indptr, plan, n_dst, sg)) return;
   const int lane = threadIdx.x & (kWave - 1);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_csr_dword_kernel(
       P[(int64_t)sg.slot * ldp + col] = acc;
     } else {
       if (dst_scale != nullptr) acc *= dst_scale[sg.row];
-      Y[sg.row * ldy + col] = acc;
+      Y[sg.row * ldy + col] = epilogue1(ep, acc, sg.row, col);
     }
   }
 }
@@ -135,7 +135,7 @@ template <bool HAS_DS>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_reduce_partials_kernel(
     const int32_t* __restrict__ plan, const float* __restrict__ P, int64_t ldp,
     const float* __restrict__ dst_scale, float* __restrict__ Y, int64_t ldy, int F,
-    int64_t items_cap) {
+    int64_t items_cap, Epilogue ep) {
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & (kWave - 1);
   const int col = (int)blockIdx.y * kWave + lane;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_reduce_partials_ke
     }
     for (; k < n; ++k) acc += p[(int64_t)k * ldp];
     if (HAS_DS) acc *= dst_scale[row];
-    Y[row * ldy + col] = acc;
+    Y[row * ldy + col] = epilogue1(ep, acc, row, col);
   }
 }
 
@@ -181,7 +181,7 @@ hipError_t launch_vec4(const SpmmArgs& a, int64_t segments, hipStream_t s) {
   hipLaunchKernelGGL((spmm_csr_vec4_kernel<LPR, V, S, K, PLANNED>), grid, block, 0, s,     \
                      a.indptr, a.indices, a.vals, a.X, a.ldx, a.src_scale, a.dst_scale,    \
                      a.Y, a.ldy, a.n_dst, (int)a.F, a.plan, a.partials, a.ldp, a.eid,      \
-                     static_cast<const KeepSeg*>(a.keep), a.n_keep)
+                     static_cast<const KeepSeg*>(a.keep), a.n_keep, a.ep)
   switch (key) {
     case 0: DGMI_LAUNCH(false, false, false); break;
     case 1: DGMI_LAUNCH(false, false, true); break;
@@ -205,7 +205,7 @@ hipError_t launch_dword(const SpmmArgs& a, int64_t segments, hipStream_t s) {
   hipLaunchKernelGGL((spmm_csr_dword_kernel<V, S, K, PLANNED>), grid, block, 0, s,         \
                      a.indptr, a.indices, a.vals, a.X, a.ldx, a.src_scale, a.dst_scale,    \
                      a.Y, a.ldy, a.n_dst, (int)a.F, a.plan, a.partials, a.ldp, a.eid,      \
-                     static_cast<const KeepSeg*>(a.keep), a.n_keep)
+                     static_cast<const KeepSeg*>(a.keep), a.n_keep, a.ep)
   switch (key) {
     case 0: DGMI_LAUNCH(false, false, false); break;
     case 1: DGMI_LAUNCH(false, false, true); break;
@@ -226,7 +226,9 @@ hipError_t dispatch(const SpmmArgs& a, int64_t segments, hipStream_t s) {
                        ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0) &&
                        ((reinterpret_cast<uintptr_t>(a.Y) & 15) == 0) &&
                        (!PLANNED || ((a.ldp % 4 == 0) &&
-                                     ((reinterpret_cast<uintptr_t>(a.partials) & 15) == 0)));
+                                     ((reinterpret_cast<uintptr_t>(a.partials) & 15) == 0))) &&
+                       (a.ep.mask == nullptr ||
+                        ((a.ep.ldm % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.ep.mask) & 15) == 0)));
   if (!aligned) return launch_dword<PLANNED>(a, segments, s);
   switch (pick_lpr(a.F)) {
     case 8: return launch_vec4<8, PLANNED>(a, segments, s);
@@ -251,10 +253,10 @@ hipError_t spmm_csr_f32(const SpmmArgs& a, hipStream_t s) {
   dim3 block(kWave * kWavesPerBlock);
   if (a.dst_scale)
     hipLaunchKernelGGL(spmm_reduce_partials_kernel<true>, grid, block, 0, s, a.plan, a.partials,
-                       a.ldp, a.dst_scale, a.Y, a.ldy, (int)a.F, items_cap);
+                       a.ldp, a.dst_scale, a.Y, a.ldy, (int)a.F, items_cap, a.ep);
   else
     hipLaunchKernelGGL(spmm_reduce_partials_kernel<false>, grid, block, 0, s, a.plan, a.partials,
-                       a.ldp, a.dst_scale, a.Y, a.ldy, (int)a.F, items_cap);
+                       a.ldp, a.dst_scale, a.Y, a.ldy, (int)a.F, items_cap, a.ep);
   return hipGetLastError();
 }
 

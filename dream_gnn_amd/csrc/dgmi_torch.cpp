@@ -100,6 +100,32 @@ Keep keep_of(const OptTensor& eid, const OptTensor& keep, int64_t nnz, const Ten
   return k;
 }
 
+// output epilogue: Y = out_mask * mask_scale * act(dst_scale * sum); act 0 none, 1 leaky-relu(slope)
+struct Epi {
+  int32_t act = 0;
+  float slope = 0.f;
+  const float* mask = nullptr;
+  int64_t ldm = 0;
+  float mscale = 1.f;
+};
+
+Epi epi_of(int64_t act, double slope, const OptTensor& out_mask, double mask_scale, int64_t rows, int64_t F, const Tensor& like) {
+  Epi e;
+  TORCH_CHECK(act == 0 || act == 1, "act must be 0 (none) or 1 (leaky-relu)");
+  e.act = (int32_t)act;
+  e.slope = (float)slope;
+  e.mscale = (float)mask_scale;
+  if (out_mask.has_value() && out_mask->defined()) {
+    check_dev(*out_mask, "out_mask");
+    TORCH_CHECK(out_mask->scalar_type() == at::kFloat && out_mask->dim() == 2 && out_mask->size(0) == rows &&
+                    out_mask->size(1) == F && out_mask->stride(1) == 1 && out_mask->device() == like.device(),
+                "out_mask must be a float32 (", rows, ", ", F, ") tensor with contiguous rows on ", like.device().str());
+    e.mask = out_mask->data_ptr<float>();
+    e.ldm = rows > 1 ? out_mask->stride(0) : (F > 0 ? F : 1);
+  }
+  return e;
+}
+
 struct Dense {
   Tensor t;
   int64_t rows, F, ld;
@@ -191,7 +217,8 @@ Tensor plan_build(const Tensor& indptr, int64_t nnz, int64_t chunk) {
 // plan undefined: dgmi_spmm_csr_f32 (a wave per row); else dgmi_spmm_csr_planned_f32
 Tensor spmm_csr_raw(const Tensor& indptr, const Tensor& indices, const OptTensor& vals, const OptTensor& eid,
                     const OptTensor& keep, const Tensor& X, const OptTensor& src_scale, const OptTensor& dst_scale,
-                    const OptTensor& plan, int64_t chunk, const OptTensor& out) {
+                    const OptTensor& plan, int64_t chunk, const OptTensor& out, int64_t act = 0, double slope = 0.0,
+                    const OptTensor& out_mask = c10::nullopt, double mask_scale = 1.0) {
   check(indptr, at::kInt, 1, "indptr", indptr);
   check(indices, at::kInt, 1, "indices", indptr);
   Dense x = dense_of(X, "X");
@@ -204,11 +231,12 @@ Tensor spmm_csr_raw(const Tensor& indptr, const Tensor& indices, const OptTensor
   c10::hip::HIPGuardMasqueradingAsCUDA guard(indptr.device());
   Tensor y = out_of(out, n_dst, x.F, indptr);
   const int64_t ldy = x.F > 0 ? x.F : 1;
+  const Epi e = epi_of(act, slope, out_mask, mask_scale, n_dst, x.F, indptr);
   if (!plan.has_value() || !plan->defined()) {
     check_status(dgmi_spmm_csr_f32(indptr.data_ptr<int32_t>(), indices.data_ptr<int32_t>(), (const float*)optptr(vals), k.eid,
                                    k.table, k.n, x.t.data_ptr<float>(), x.ld, (const float*)optptr(src_scale),
-                                   (const float*)optptr(dst_scale), y.data_ptr<float>(), ldy, n_dst, x.rows, x.F,
-                                   stream_of(indptr)), "dgmi_spmm_csr_f32");
+                                   (const float*)optptr(dst_scale), y.data_ptr<float>(), ldy, n_dst, x.rows, x.F, e.act,
+                                   e.slope, e.mask, e.ldm, e.mscale, stream_of(indptr)), "dgmi_spmm_csr_f32");
     return y;
   }
   const size_t pbytes = dgmi_spmm_partials_bytes(nnz, (int32_t)chunk, x.F);
@@ -216,14 +244,16 @@ Tensor spmm_csr_raw(const Tensor& indptr, const Tensor& indices, const OptTensor
   check_status(dgmi_spmm_csr_planned_f32(indptr.data_ptr<int32_t>(), indices.data_ptr<int32_t>(), (const float*)optptr(vals),
                                          k.eid, k.table, k.n, x.t.data_ptr<float>(), x.ld, (const float*)optptr(src_scale),
                                          (const float*)optptr(dst_scale), y.data_ptr<float>(), ldy, n_dst, x.rows, x.F, nnz,
-                                         (int32_t)chunk, plan->data_ptr(), partials.data_ptr(), pbytes, stream_of(indptr)),
+                                         (int32_t)chunk, plan->data_ptr(), partials.data_ptr(), pbytes, e.act, e.slope, e.mask,
+                                         e.ldm, e.mscale, stream_of(indptr)),
                "dgmi_spmm_csr_planned_f32");
   return y;
 }
 
 Tensor spmm_sliced_raw(const Tensor& segptr, const Tensor& indices, const OptTensor& vals, const OptTensor& eid,
                        const OptTensor& keep, const Tensor& X, const OptTensor& src_scale, const OptTensor& dst_scale,
-                       int64_t n_dst, int64_t n_slices, const OptTensor& out) {
+                       int64_t n_dst, int64_t n_slices, const OptTensor& out, int64_t act = 0, double slope = 0.0,
+                       const OptTensor& out_mask = c10::nullopt, double mask_scale = 1.0) {
   check(segptr, at::kInt, 1, "segptr", segptr);
   check(indices, at::kInt, 1, "indices", segptr);
   TORCH_CHECK(segptr.numel() == n_slices * n_dst + 1, "segptr has ", segptr.numel(), " entries, expected n_slices * n_dst + 1");
@@ -236,12 +266,14 @@ Tensor spmm_sliced_raw(const Tensor& segptr, const Tensor& indices, const OptTen
   const Keep k = keep_of(eid, keep, nnz, segptr);
   c10::hip::HIPGuardMasqueradingAsCUDA guard(segptr.device());
   Tensor y = out_of(out, n_dst, x.F, segptr);
+  const Epi e = epi_of(act, slope, out_mask, mask_scale, n_dst, x.F, segptr);
   const size_t pbytes = dgmi_spmm_sliced_planes_bytes(n_dst, (int32_t)n_slices, x.F);
   Tensor planes = scratch(segptr, pbytes, kPlanes);
   check_status(dgmi_spmm_sliced_f32(segptr.data_ptr<int32_t>(), indices.data_ptr<int32_t>(), (const float*)optptr(vals), k.eid,
                                     k.table, k.n, x.t.data_ptr<float>(), x.ld, (const float*)optptr(src_scale),
                                     (const float*)optptr(dst_scale), y.data_ptr<float>(), x.F, n_dst, x.rows, x.F,
-                                    (int32_t)n_slices, planes.data_ptr(), pbytes, stream_of(segptr)), "dgmi_spmm_sliced_f32");
+                                    (int32_t)n_slices, planes.data_ptr(), pbytes, e.act, e.slope, e.mask, e.ldm, e.mscale,
+                                    stream_of(segptr)), "dgmi_spmm_sliced_f32");
   return y;
 }
 
@@ -284,6 +316,22 @@ Tensor gather_add_raw(const Tensor& src, const Tensor& dst, const Tensor& A, con
   check_status(dgmi_gather_add_f32(src.data_ptr<int32_t>(), dst.data_ptr<int32_t>(), E, a.t.data_ptr<float>(), a.ld,
                                    b.t.data_ptr<float>(), b.ld, (const float*)optptr(bias), a.F, out.data_ptr<float>(),
                                    a.F > 0 ? a.F : 1, stream_of(src)), "dgmi_gather_add_f32");
+  return out;
+}
+
+Tensor epilogue_backward(const Tensor& dY, const Tensor& Y, const OptTensor& mask, int64_t act, double slope, double mask_scale) {
+  check_dev(dY, "dY");
+  TORCH_CHECK(dY.scalar_type() == at::kFloat && dY.is_contiguous(), "dY must be contiguous float32");
+  TORCH_CHECK(Y.scalar_type() == at::kFloat && Y.is_contiguous() && Y.numel() == dY.numel() && Y.device() == dY.device(),
+              "Y must be contiguous float32 of dY's size, on its device");
+  if (mask.has_value() && mask->defined())
+    TORCH_CHECK(mask->scalar_type() == at::kFloat && mask->is_contiguous() && mask->numel() == dY.numel() &&
+                    mask->device() == dY.device(), "mask must be contiguous float32 of dY's size, on its device");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(dY.device());
+  Tensor out = at::empty_like(dY);
+  check_status(dgmi_epilogue_backward_f32(dY.data_ptr<float>(), Y.data_ptr<float>(), (const float*)optptr(mask), dY.numel(),
+                                          (int32_t)act, (float)slope, (float)mask_scale, out.data_ptr<float>(), stream_of(dY)),
+               "dgmi_epilogue_backward_f32");
   return out;
 }
 
@@ -336,22 +384,25 @@ Tensor keep_mask(const Tensor& keep, int64_t E) {
 }
 
 Tensor spmm_csr_new(const Tensor& indptr, const Tensor& indices, const OptTensor& vals, const OptTensor& eid, const OptTensor& keep,
-                    const Tensor& X, const OptTensor& ss, const OptTensor& ds, const OptTensor& plan, int64_t chunk) {
-  return spmm_csr_raw(indptr, indices, vals, eid, keep, X, ss, ds, plan, chunk, c10::nullopt);
+                    const Tensor& X, const OptTensor& ss, const OptTensor& ds, const OptTensor& plan, int64_t chunk,
+                    int64_t act, double slope, const OptTensor& out_mask, double mask_scale) {
+  return spmm_csr_raw(indptr, indices, vals, eid, keep, X, ss, ds, plan, chunk, c10::nullopt, act, slope, out_mask, mask_scale);
 }
 void spmm_csr_out(const Tensor& indptr, const Tensor& indices, const OptTensor& vals, const OptTensor& eid, const OptTensor& keep,
-                  const Tensor& X, const OptTensor& ss, const OptTensor& ds, const OptTensor& plan, int64_t chunk, Tensor out) {
-  spmm_csr_raw(indptr, indices, vals, eid, keep, X, ss, ds, plan, chunk, out);
+                  const Tensor& X, const OptTensor& ss, const OptTensor& ds, const OptTensor& plan, int64_t chunk, Tensor out,
+                  int64_t act, double slope, const OptTensor& out_mask, double mask_scale) {
+  spmm_csr_raw(indptr, indices, vals, eid, keep, X, ss, ds, plan, chunk, out, act, slope, out_mask, mask_scale);
 }
 Tensor spmm_sliced_new(const Tensor& segptr, const Tensor& indices, const OptTensor& vals, const OptTensor& eid,
                        const OptTensor& keep, const Tensor& X, const OptTensor& ss, const OptTensor& ds, int64_t n_dst,
-                       int64_t n_slices) {
-  return spmm_sliced_raw(segptr, indices, vals, eid, keep, X, ss, ds, n_dst, n_slices, c10::nullopt);
+                       int64_t n_slices, int64_t act, double slope, const OptTensor& out_mask, double mask_scale) {
+  return spmm_sliced_raw(segptr, indices, vals, eid, keep, X, ss, ds, n_dst, n_slices, c10::nullopt, act, slope, out_mask,
+                         mask_scale);
 }
 void spmm_sliced_out(const Tensor& segptr, const Tensor& indices, const OptTensor& vals, const OptTensor& eid,
                      const OptTensor& keep, const Tensor& X, const OptTensor& ss, const OptTensor& ds, int64_t n_dst,
-                     int64_t n_slices, Tensor out) {
-  spmm_sliced_raw(segptr, indices, vals, eid, keep, X, ss, ds, n_dst, n_slices, out);
+                     int64_t n_slices, Tensor out, int64_t act, double slope, const OptTensor& out_mask, double mask_scale) {
+  spmm_sliced_raw(segptr, indices, vals, eid, keep, X, ss, ds, n_dst, n_slices, out, act, slope, out_mask, mask_scale);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -410,13 +461,16 @@ TORCH_LIBRARY(dreamgnn_mi, m) {
   m.def("plan_build(Tensor indptr, int nnz, int chunk) -> Tensor");
   m.def("spmm_csr(Tensor indptr, Tensor indices, Tensor? vals, Tensor X, Tensor? src_scale=None, Tensor? dst_scale=None) -> Tensor");
   m.def("spmm_csr_raw(Tensor indptr, Tensor indices, Tensor? vals, Tensor? eid, Tensor? keep, Tensor X, Tensor? src_scale, "
-        "Tensor? dst_scale, Tensor? plan, int chunk) -> Tensor");
+        "Tensor? dst_scale, Tensor? plan, int chunk, int act=0, float slope=0., Tensor? out_mask=None, float mask_scale=1.) -> Tensor");
   m.def("spmm_csr_out(Tensor indptr, Tensor indices, Tensor? vals, Tensor? eid, Tensor? keep, Tensor X, Tensor? src_scale, "
-        "Tensor? dst_scale, Tensor? plan, int chunk, Tensor(a!) out) -> ()");
+        "Tensor? dst_scale, Tensor? plan, int chunk, Tensor(a!) out, int act=0, float slope=0., Tensor? out_mask=None, "
+        "float mask_scale=1.) -> ()");
   m.def("spmm_sliced_raw(Tensor segptr, Tensor indices, Tensor? vals, Tensor? eid, Tensor? keep, Tensor X, Tensor? src_scale, "
-        "Tensor? dst_scale, int n_dst, int n_slices) -> Tensor");
+        "Tensor? dst_scale, int n_dst, int n_slices, int act=0, float slope=0., Tensor? out_mask=None, float mask_scale=1.) -> Tensor");
   m.def("spmm_sliced_out(Tensor segptr, Tensor indices, Tensor? vals, Tensor? eid, Tensor? keep, Tensor X, Tensor? src_scale, "
-        "Tensor? dst_scale, int n_dst, int n_slices, Tensor(a!) out) -> ()");
+        "Tensor? dst_scale, int n_dst, int n_slices, Tensor(a!) out, int act=0, float slope=0., Tensor? out_mask=None, "
+        "float mask_scale=1.) -> ()");
+  m.def("epilogue_backward(Tensor dY, Tensor Y, Tensor? mask, int act, float slope, float mask_scale) -> Tensor");
   m.def("gather_f32(Tensor values, Tensor perm) -> Tensor");
   m.def("gather_concat_raw(Tensor src, Tensor dst, Tensor A, Tensor B) -> Tensor");
   m.def("gather_add_raw(Tensor src, Tensor dst, Tensor A, Tensor B, Tensor? bias) -> Tensor");
@@ -435,6 +489,7 @@ TORCH_LIBRARY_IMPL(dreamgnn_mi, CUDA, m) {
   m.impl("spmm_csr_out", spmm_csr_out);
   m.impl("spmm_sliced_raw", spmm_sliced_new);
   m.impl("spmm_sliced_out", spmm_sliced_out);
+  m.impl("epilogue_backward", epilogue_backward);
   m.impl("gather_f32", gather_f32);
   m.impl("gather_concat_raw", gather_concat_raw);
   m.impl("gather_add_raw", gather_add_raw);

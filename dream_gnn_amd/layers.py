@@ -271,11 +271,28 @@ class GCMCLayer(nn.Module):
         inputs = {"drug": drug_feat, "disease": dis_feat}
         graph = _as_hetero(graph)
         out = self._fused_conv(graph, inputs, mod_args) if self.fuse_relations and self.agg == "sum" else None
+        if out is not None and out.get("_epilogue_done"):
+            return self.ifc(out["drug"]), self.ufc(out["disease"])  # agg_act + dropout ran inside the products
         if out is None:
             out = self.conv(graph, inputs, mod_args=mod_args)
         drug = self.dropout(self.agg_act(out["drug"]))
         dis = self.dropout(self.agg_act(out["disease"]))
         return self.ifc(drug), self.ufc(dis)
+
+    #: f3 epilogue — `dropout(agg_act(sum over relations))` (layers.py:134-138) inside the kernel that
+    #: writes the aggregated messages.  Needs an activation the kernels know (LeakyReLU / ReLU / none).
+    fuse_epilogue = True
+
+    def _epilogue_spec(self):
+        """(act, slope) the kernels can apply for ``self.agg_act``, or None."""
+        a = self.agg_act
+        if isinstance(a, nn.LeakyReLU):
+            return 1, float(a.negative_slope)
+        if isinstance(a, nn.ReLU):
+            return 1, 0.0
+        if not isinstance(a, nn.Module) and getattr(a, "__name__", "") == "<lambda>" and a(0) == 0 and a(-2.5) == -2.5:
+            return 0, 0.0  # get_activation(None): the identity
+        return None
 
     def _fused_conv(self, graph, inputs, mod_args):
         """sum_r ci * A_r (dropout_r(cj) * X W_r) per destination type in one launch each.
@@ -326,6 +343,22 @@ class GCMCLayer(nn.Module):
         # as the per-slice path does (layers.py:224)
         drops = {can: self.conv.mods[can[1]].dropout(graph[can].srcdata["cj"]).view(-1)
                  for can in graph.canonical_etypes}
+        # Layer-level dropout masks (layers.py:134-135), drawn here — after the per-relation draws, drug
+        # before disease, exactly where the reference's RNG stream has them — and applied, with the
+        # activation, by the products' last kernels.
+        spec = self._epilogue_spec() if self.fuse_epilogue and set(plans) == {"drug", "disease"} else None
+        masks = {}
+        if spec is not None:
+            p = self.dropout.p if self.training else 0.0
+            for nt in ("drug", "disease"):
+                csr, cans = plans[nt]
+                width = weights[cans[0]].shape[1]
+                m = None
+                if p > 0:
+                    m = torch.empty((csr.n_dst, width), dtype=torch.float32, device=inputs[cans[0][0]].device).bernoulli_(1 - p)
+                    if -width % 4:
+                        m = F.pad(m, (0, -width % 4))
+                masks[nt] = (m, 1.0 / (1.0 - p) if p > 0 else 1.0)
         out = {}
         for nt, (csr, cans) in plans.items():
             x = inputs[cans[0][0]]
@@ -334,8 +367,14 @@ class GCMCLayer(nn.Module):
             w_cat = torch.cat([F.pad(weights[c], (0, pad)) if pad else weights[c] for c in cans], dim=1)
             feat = torch.matmul(x, w_cat).view(x.shape[0] * len(cans), width + pad)  # rows [u][r]
             scale = torch.stack([drops[c] for c in cans], dim=1).reshape(-1)
-            y = ops.spmm_csr(csr, feat, src_scale=scale, dst_scale=graph[cans[0]].dstdata["ci"])
+            ci = graph[cans[0]].dstdata["ci"]
+            if spec is not None:
+                y = ops.spmm_csr_act_dropout(csr, feat, scale, ci, spec[0], spec[1], *masks[nt])
+            else:
+                y = ops.spmm_csr(csr, feat, src_scale=scale, dst_scale=ci)
             out[nt] = y if not pad else y[:, :width]
+        if spec is not None:
+            out["_epilogue_done"] = True
         return out
 
 

@@ -25,6 +25,9 @@ from . import _lib
 _L = _lib.lib          # ctypes view of the C ABI: host-only size / geometry queries
 _T = _lib.torch_ops    # torch.ops.dreamgnn_mi: the dispatcher ops the kernels are launched through
 _NULLCTX = contextlib.nullcontext()
+#: output epilogue of a product: (act, slope, out_mask, mask_scale) — act 0 none / 1 leaky-relu(slope);
+#: out_mask: 0/1 keep mask of the output (dropout), multiplied in with mask_scale = 1 / (1 - p)
+_NO_EPI = (0, 0.0, None, 1.0)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -116,16 +119,17 @@ def build_plan(indptr: torch.Tensor, nnz: int, chunk: Optional[int] = None) -> S
 
 
 def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx,
-                 eid=None, keep=None):
+                 eid=None, keep=None, epi=None):
     """One ``dreamgnn_mi::spmm_csr_raw`` / ``spmm_csr_out`` dispatch (-> ``dgmi_spmm_csr_f32`` or
     ``dgmi_spmm_csr_planned_f32`` on torch's current stream; dtype / shape / device checks, output
     and scratch allocation happen in the op).  ``keep``: (n, 8) int32 subset descriptions
     (``random_subset_select``) applied through ``eid`` on the fly."""
     args = (indptr, indices, vals, eid if keep is not None else None, keep, X, src_scale, dst_scale,
             None if plan is None else plan.buf, 0 if plan is None else plan.chunk)
+    epi = epi or _NO_EPI
     if out is None:
-        return _T.spmm_csr_raw(*args)
-    _T.spmm_csr_out(*args, out)
+        return _T.spmm_csr_raw(*args, *epi)
+    _T.spmm_csr_out(*args, out, *epi)
     return out
 
 
@@ -194,9 +198,10 @@ class SlicedCSR:
 
     _DEFAULT = object()
 
-    def spmm(self, X, src_scale=None, dst_scale=None, out=None, vals=_DEFAULT, keep=None):
+    def spmm(self, X, src_scale=None, dst_scale=None, out=None, vals=_DEFAULT, keep=None, epi=None):
         """``vals`` (in sliced order, see ``eid``) overrides the values given at construction;
-        ``keep``: subset descriptions applied through ``eid`` (edge dropout on the fly)."""
+        ``keep``: subset descriptions applied through ``eid`` (edge dropout on the fly); ``epi``: output
+        epilogue (act, slope, out_mask, mask_scale) applied by the plane-reduce kernel."""
         vals = self.vals if vals is SlicedCSR._DEFAULT else vals
         if not X.is_cuda or X.device != self.segptr.device:
             _require_device(self.segptr, X)
@@ -205,9 +210,10 @@ class SlicedCSR:
         args = (self.segptr, self.indices, vals, self.eid if keep is not None else None,
                 None if keep is None else _prep_keep(keep), X, None if src_scale is None else src_scale.reshape(-1),
                 None if dst_scale is None else dst_scale.reshape(-1), self.n_dst, self.n_slices)
+        epi = epi or _NO_EPI
         if out is None:
-            return _T.spmm_sliced_raw(*args)
-        _T.spmm_sliced_out(*args, out)
+            return _T.spmm_sliced_raw(*args, *epi)
+        _T.spmm_sliced_out(*args, out, *epi)
         return out
 
 
@@ -222,7 +228,11 @@ FORCE_KERNEL = {"planned": "planned", "sliced": "sliced", "dense": "dense"}.get(
 # bipartite block (lrssl: 464 897 of 519 603 cells) — "a dense-block tile actually materialises"
 # (north_star), and a plain fp32 GEMM through hipBLASLt beats any gather.  Taken when at least
 # DENSE_MIN_DENSITY of the cells hold an edge and the dense matrix stays small.
-DENSE_MIN_DENSITY = 0.25
+# Measured (round 2, tools/step_ab.py, in-process A/B on an lrssl-shaped model): through torch.mm the dense
+# form is SLOWER than the planned CSR kernel in context — eval forward 2.08 vs 1.93 ms, training step with
+# edge dropout +0.55 ms (the dense matrix of a dropped view is rebuilt every step) — so it is opt-in:
+# DENSE_MIN_DENSITY = 0.25 enables it (DGMI_DENSE_MIN_DENSITY); the default never selects it.
+DENSE_MIN_DENSITY = float(os.environ.get("DGMI_DENSE_MIN_DENSITY", "2.0"))
 DENSE_MAX_CELLS = 1 << 24  # 64 MB of fp32
 # Round 2 (tools/cfg5_forms_probe.py): on the node-scaled config-5 shards the sliced pair still wins at
 # 204 MB / degree 100 (0.737 vs 0.784 ms) and 409 MB / degree 200 (0.739 vs 0.820 ms), and loses badly
@@ -271,13 +281,13 @@ class _SplitSliced:
         self.c_plan = build_plan(self.c_indptr, self.n_virtual)
         self.n_rows = n_rows
 
-    def spmm(self, X, src_scale, dst_scale, out, vals, keep=None):
+    def spmm(self, X, src_scale, dst_scale, out, vals, keep=None, epi=None):
         yv = self.sliced.spmm(X, src_scale, None, None, vals=vals, keep=keep)
         F = yv.shape[1]
         if out is None:
             out = torch.empty((self.n_rows, F), dtype=torch.float32, device=yv.device)
         return _launch_spmm(yv.device, self.c_indptr, self.c_indices, None, yv, None, dst_scale, out, self.c_plan,
-                            self.n_rows, self.n_virtual, F, F)
+                            self.n_rows, self.n_virtual, F, F, epi=epi)
 
 
 class CSRGraph:
@@ -449,7 +459,7 @@ class CSRGraph:
         indptr_t, indices_t, eid_t, plan_t = self._t_struct()
         return indptr_t, indices_t, self._vals_for("csr_t", eid_t), plan_t
 
-    def _run(self, indptr, indices, vals, plan, n_rows, n_cols, X, col_scale, row_scale, out, eid=None):
+    def _run(self, indptr, indices, vals, plan, n_rows, n_cols, X, col_scale, row_scale, out, eid=None, epi=None):
         dev = indptr.device
         if not X.is_cuda or X.device != dev:
             _require_device(indptr, X)
@@ -457,7 +467,7 @@ class CSRGraph:
             raise RuntimeError("X has %d rows, the graph has %d source nodes" % (X.shape[0], n_cols))
         return _launch_spmm(dev, indptr, indices, vals, X, None if col_scale is None else col_scale.reshape(-1),
                             None if row_scale is None else row_scale.reshape(-1), out, plan, n_rows, n_cols, 0, 0,
-                            eid if self._keep is not None else None, self._keep)
+                            eid if self._keep is not None else None, self._keep, epi)
 
     # -- dense fast path ----------------------------------------------------------------------------
     def _use_dense(self) -> bool:
@@ -465,7 +475,10 @@ class CSRGraph:
         cells = S.n_dst * S.n_src
         if FORCE_KERNEL is not None:
             return FORCE_KERNEL == "dense" and 0 < cells <= DENSE_MAX_CELLS
-        return 0 < cells <= DENSE_MAX_CELLS and self.nnz >= DENSE_MIN_DENSITY * cells
+        # An edge-dropped view would have to rebuild its dense matrix every training step (mask pass +
+        # 2 MB memset + scatter-add): measured 0.55 ms per lrssl-shaped step MORE than letting the CSR
+        # kernels skip the dropped edges on the fly — the dense form is for graphs that stay put.
+        return self._keep is None and 0 < cells <= DENSE_MAX_CELLS and self.nnz >= DENSE_MIN_DENSITY * cells
 
     def _dense_matrix(self) -> torch.Tensor:
         """A as a dense (n_dst, n_src) fp32 matrix of THIS view: entry = sum of the values (1 when
@@ -485,7 +498,7 @@ class CSRGraph:
             self.__dict__["_dense"] = A
         return A
 
-    def _dense_product(self, transposed: bool, X, col_scale, row_scale, out):
+    def _dense_product(self, transposed: bool, X, col_scale, row_scale, out, epi=None):
         """``diag(row_scale) M diag(col_scale) X`` with M = A or A^T as one fp32 GEMM (hipBLASLt through
         torch.mm).  Differs from the gather kernels only where X holds Inf / NaN in rows no edge
         touches (0 * Inf): finite inputs agree to fp32 rounding."""
@@ -496,27 +509,35 @@ class CSRGraph:
         Y = torch.mm(M, X, out=out) if out is not None else torch.mm(M, X)
         if row_scale is not None:
             Y.mul_(row_scale.reshape(-1, 1))
+        if epi is not None:
+            act, slope, mask, mscale = epi
+            if act == 1:
+                Y = torch.nn.functional.leaky_relu_(Y, slope)
+            if mask is not None:
+                Y.mul_(mask).mul_(mscale)
         return Y
 
-    def spmm(self, X, src_scale=None, dst_scale=None, out=None):
+    def spmm(self, X, src_scale=None, dst_scale=None, out=None, epi=None):
         """``diag(dst_scale) A diag(src_scale) X`` (no autograd).  Picks the dense GEMM for
         near-complete blocks, the XCD-local sliced kernel when the feature table is a few L2s large
-        and the graph is regular, else the planned kernel."""
+        and the graph is regular, else the planned kernel.  ``epi``: output epilogue
+        (act, slope, out_mask, mask_scale), fused into the kernel that writes the result."""
         S = self._S
         if X.dim() == 2 and self._use_dense():
             if not X.is_cuda or X.device != S.indptr.device:
                 _require_device(S.indptr, X)
-            return self._dense_product(False, X, src_scale, dst_scale, out)
+            return self._dense_product(False, X, src_scale, dst_scale, out, epi)
         if X.dim() == 2 and self._use_sliced(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
             if S.sliced is None:
                 S.sliced = SlicedCSR(S.dst, S.src, S.n_dst, S.n_src)
-            return S.sliced.spmm(X, src_scale, dst_scale, out, vals=self._vals_for("sliced", S.sliced.eid), keep=self._keep)
+            return S.sliced.spmm(X, src_scale, dst_scale, out, vals=self._vals_for("sliced", S.sliced.eid), keep=self._keep,
+                                 epi=epi)
         if X.dim() == 2 and self._use_split(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
             if S.split is None:
                 S.split = _SplitSliced(S.indptr, S.eid, S.src, S.n_dst, S.n_src)
             return S.split.spmm(X, _prep_scale(src_scale, S.n_src, "src_scale"), _prep_scale(dst_scale, S.n_dst, "dst_scale"),
-                                out, self._vals_for("split", S.split.sliced.eid), keep=self._keep)
-        return self._run(S.indptr, S.indices, self.vals, S.plan, S.n_dst, S.n_src, X, src_scale, dst_scale, out, S.eid)
+                                out, self._vals_for("split", S.split.sliced.eid), keep=self._keep, epi=epi)
+        return self._run(S.indptr, S.indices, self.vals, S.plan, S.n_dst, S.n_src, X, src_scale, dst_scale, out, S.eid, epi)
 
     def spmm_t(self, dY, src_scale=None, dst_scale=None, out=None):
         """``diag(src_scale) A^T diag(dst_scale) dY`` — the backward of :meth:`spmm`."""
@@ -559,6 +580,43 @@ class _SpMM(torch.autograd.Function):
             # edges with the two scales swapped.
             dX = ctx.g.spmm_t(dY, src_scale, dst_scale)
         return dX, None, None, None
+
+
+class _SpMMEpilogue(torch.autograd.Function):
+    """``mask * mask_scale * act(diag(ds) A diag(ss) X)`` with the activation and the dropout mask
+    applied by the kernel that writes the product (f3, reference layers.py:134-138)."""
+
+    @staticmethod
+    def forward(ctx, X, g: CSRGraph, src_scale, dst_scale, act, slope, mask, mask_scale):
+        y = g.spmm(X, src_scale, dst_scale, epi=(act, slope, mask, mask_scale))
+        ctx.g, ctx.epi = g, (act, slope, mask_scale)
+        ctx.save_for_backward(src_scale, dst_scale, y, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dY):
+        src_scale, dst_scale, y, mask = ctx.saved_tensors
+        act, slope, mask_scale = ctx.epi
+        dX = None
+        if ctx.needs_input_grad[0]:
+            g_pre = epilogue_backward(dY.contiguous(), y, mask, act, slope, mask_scale)
+            dX = ctx.g.spmm_t(g_pre, src_scale, dst_scale)
+        return dX, None, None, None, None, None, None, None
+
+
+def epilogue_backward(dY, Y, mask, act, slope, mask_scale):
+    """``dY * act'(Y) * mask * mask_scale`` in one pass (``dgmi_epilogue_backward_f32``)."""
+    _require_device(dY, Y, mask)
+    return _T.epilogue_backward(dY, Y, mask, act, slope, mask_scale)
+
+
+def spmm_csr_act_dropout(g: CSRGraph, X, src_scale=None, dst_scale=None, act: int = 0, slope: float = 0.0,
+                         mask: Optional[torch.Tensor] = None, mask_scale: float = 1.0) -> torch.Tensor:
+    """:func:`spmm_csr` followed by ``leaky_relu`` (``act=1``) and a dropout keep ``mask`` (0/1 floats of
+    the output's shape, scaled by ``mask_scale``), both inside the product's last kernel."""
+    if src_scale is not None and src_scale.requires_grad or dst_scale is not None and dst_scale.requires_grad:
+        raise RuntimeError("spmm_csr: gradients w.r.t. the diagonal scales are not part of the path")
+    return _SpMMEpilogue.apply(X, g, src_scale, dst_scale, act, slope, mask, mask_scale)
 
 
 def spmm_csr(g: CSRGraph, X: torch.Tensor, src_scale: Optional[torch.Tensor] = None,

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 10
+#define DGMI_ABI_VERSION 11
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -119,13 +119,20 @@ DGMI_API int dgmi_csr_from_coo_i32(const int32_t* row, const int32_t* col, int64
  * dgmi_random_subset_select (one per independently dropped edge list; several when a layout
  * concatenates relations).  Dropped edges are skipped — their source rows are not read into the
  * sum, so Inf / NaN there do not leak (unlike a 0/1 value mask).  n_keep == 0: eid, keep unused.
+ *
+ * Output epilogue (all three SpMM entry points), fused into the kernel that writes Y —
+ * GCMCLayer's `dropout(agg_act(...))` on the aggregated messages (layers.py:134-138):
+ *   Y[v, c] = out_mask[v * ld_mask + c] * out_mask_scale * act(dst_scale[v] * sum)
+ * act: 0 = none, 1 = leaky-relu with act_slope (v > 0 ? v : v * slope; slope 0 = relu);
+ * out_mask (nullable): the dropout keep mask, 0/1 floats, out_mask_scale = 1 / (1 - p).
  */
 DGMI_API int dgmi_spmm_csr_f32(const int32_t* indptr, const int32_t* indices,
                       const float* vals, const int32_t* eid, const uint32_t* keep, int32_t n_keep,
                       const float* X, int64_t ldx,
                       const float* src_scale, const float* dst_scale, float* Y,
                       int64_t ldy, int64_t n_dst, int64_t n_src, int64_t F,
-                      dgmi_stream_t stream);
+                      int32_t act, float act_slope, const float* out_mask, int64_t ld_mask,
+                      float out_mask_scale, dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
  * Planned SpMM: the same product with an nnz-balanced launch.
@@ -160,7 +167,8 @@ DGMI_API int dgmi_spmm_csr_planned_f32(const int32_t* indptr, const int32_t* ind
                                        int64_t ldy, int64_t n_dst, int64_t n_src, int64_t F,
                                        int64_t nnz, int32_t chunk, const void* plan,
                                        void* partials, size_t partials_bytes,
-                                       dgmi_stream_t stream);
+                                       int32_t act, float act_slope, const float* out_mask,
+                                       int64_t ld_mask, float out_mask_scale, dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
  * Gather of per-edge values through a permutation: out[p] = in[perm[p]].
@@ -198,7 +206,9 @@ DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices,
                                   const float* X, int64_t ldx, const float* src_scale,
                                   const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
                                   int64_t n_src, int64_t F, int32_t n_slices, void* planes,
-                                  size_t planes_bytes, dgmi_stream_t stream);
+                                  size_t planes_bytes, int32_t act, float act_slope,
+                                  const float* out_mask, int64_t ld_mask, float out_mask_scale,
+                                  dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
  * (f2) Per-edge gather-concat: out[e, 0:Fa] = A[src[e], :], out[e, Fa:Fa+Fb] = B[dst[e], :].
@@ -226,6 +236,15 @@ DGMI_API int dgmi_gather_concat_f32(const int32_t* src, const int32_t* dst, int6
 DGMI_API int dgmi_gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
                                  int64_t lda, const float* B, int64_t ldb, const float* bias,
                                  int64_t F, float* out, int64_t ldo, dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
+ * Backward of the fused output epilogue over n contiguous elements:
+ *   out[i] = dY[i] * (act == 1 ? (Y[i] > 0 ? 1 : act_slope) : 1) * (mask ? mask[i] * mask_scale : 1)
+ * where Y is the epilogue's output (layers.py:134-138 backward: dropout then activation).
+ */
+DGMI_API int dgmi_epilogue_backward_f32(const float* dY, const float* Y, const float* mask, int64_t n,
+                                        int32_t act, float act_slope, float mask_scale, float* out,
+                                        dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
  * (D3) Edge dropout selection: a uniformly random subset of exactly `keep` of E edges — what

@@ -76,11 +76,23 @@ def keep_mask(desc, E):
 
 
 def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan, n_dst, n_src, F, ldx,
-                 eid=None, keep=None):
+                 eid=None, keep=None, epi=None):
     if keep is not None:  # edge dropout on the fly: position p takes part iff keep(eid[p])
         m = keep_mask(keep, int(eid.max()) + 1 if eid.numel() else 0)[eid.long()]
         vals = m if vals is None else vals * m
-    return spmm_csr_raw(indptr, indices, vals, X, src_scale, dst_scale, out=out)
+    y = spmm_csr_raw(indptr, indices, vals, X, src_scale, dst_scale, out=out)
+    if epi is not None:  # the kernels' output epilogue: activation, then the dropout keep mask
+        act, slope, mask, mscale = epi
+        if act == 1:
+            y = torch.nn.functional.leaky_relu_(y, slope)
+        if mask is not None:
+            y.mul_(mask).mul_(mscale)
+    return y
+
+
+def epilogue_backward(dY, Y, mask, act, slope, mask_scale):
+    g = torch.where(Y > 0, dY, dY * slope) if act == 1 else dY.clone()
+    return g if mask is None else g * mask * mask_scale
 
 
 @contextlib.contextmanager
@@ -88,7 +100,7 @@ def patched():
     from dream_gnn_amd import ops
 
     names = ("csr_from_coo", "gather_f32", "spmm_csr_raw", "_launch_spmm", "_require_device", "build_plan", "FORCE_KERNEL",
-             "gather_concat_raw", "gather_add_raw", "random_subset_mask", "random_subset_select", "random_subset_select_batch", "keep_mask")
+             "gather_concat_raw", "gather_add_raw", "random_subset_mask", "random_subset_select", "random_subset_select_batch", "keep_mask", "epilogue_backward")
     saved = {k: getattr(ops, k) for k in names}
     ops.csr_from_coo, ops.gather_f32, ops.spmm_csr_raw = csr_from_coo, gather_f32, spmm_csr_raw
     ops._launch_spmm = _launch_spmm
@@ -98,6 +110,7 @@ def patched():
     ops.random_subset_select = random_subset_select
     ops.random_subset_select_batch = random_subset_select_batch
     ops.keep_mask = keep_mask
+    ops.epilogue_backward = epilogue_backward
     ops._require_device = lambda *ts: next((t.device for t in ts if t is not None), None)
     ops.build_plan = lambda indptr, nnz, chunk=None: None  # launch plans are a device-side concern
     ops.FORCE_KERNEL = "planned"  # the sliced layout is a device-side concern too

@@ -17,7 +17,7 @@ def _declared():
 
 def test_header_declares_the_expected_entry_points():
     assert _declared() == ["dgmi_abi_version", "dgmi_csr_from_coo_i32", "dgmi_csr_sliced_from_coo_i32",
-                           "dgmi_device_ok", "dgmi_gather_add_f32", "dgmi_gather_concat_f32",
+                           "dgmi_device_ok", "dgmi_epilogue_backward_f32", "dgmi_gather_add_f32", "dgmi_gather_concat_f32",
                            "dgmi_gather_f32", "dgmi_keep_mask_f32", "dgmi_probe_row_gather_f32",
                            "dgmi_random_subset_mask_f32", "dgmi_random_subset_select", "dgmi_random_subset_select_batch",
                            "dgmi_random_subset_workspace_bytes",
@@ -55,13 +55,14 @@ def test_argument_validation_returns_codes_without_a_gpu():
     assert L.dgmi_csr_from_coo_i32(None, None, 1, 4, 0, None, None, None, None, None, None) == -1
     assert L.dgmi_csr_from_coo_i32(None, None, 2 ** 31, 4, 0, None, None, None, None, ctypes.byref(need), None) == -2
     K0 = (None, None, 0)  # no edge dropout on the fly: eid, keep, n_keep
-    assert L.dgmi_spmm_csr_f32(None, None, None, *K0, None, 4, None, None, None, 4, -1, 1, 4, None) == -1
-    assert L.dgmi_spmm_csr_f32(None, None, None, *K0, None, 4, None, None, None, 4, 2, 2, 4, None) == -1  # null indptr/Y
-    assert L.dgmi_spmm_csr_f32(None, None, None, *K0, None, 4, None, None, None, 4, 0, 0, 4, None) == 0   # empty problem
-    assert L.dgmi_spmm_csr_f32(16, 16, None, *K0, 16, 2, None, None, 32, 4, 2, 2, 4, None) == -1          # ldx < F
-    assert L.dgmi_spmm_csr_f32(16, 16, None, *K0, 64, 4, None, None, 64, 4, 2, 2, 4, None) == -1          # Y aliases X
-    assert L.dgmi_spmm_csr_f32(16, 16, None, None, 16, 1, 16, 4, None, None, 32, 4, 2, 2, 4, None) == -1  # keep without eid
-    assert L.dgmi_spmm_csr_f32(16, 16, None, 16, 16, 9, 16, 4, None, None, 32, 4, 2, 2, 4, None) == -1    # > 8 descriptions
+    E0 = (0, 0.0, None, 0, 1.0)  # no epilogue: act, act_slope, out_mask, ld_mask, out_mask_scale
+    assert L.dgmi_spmm_csr_f32(None, None, None, *K0, None, 4, None, None, None, 4, -1, 1, 4, *E0, None) == -1
+    assert L.dgmi_spmm_csr_f32(None, None, None, *K0, None, 4, None, None, None, 4, 2, 2, 4, *E0, None) == -1  # null indptr/Y
+    assert L.dgmi_spmm_csr_f32(None, None, None, *K0, None, 4, None, None, None, 4, 0, 0, 4, *E0, None) == 0   # empty problem
+    assert L.dgmi_spmm_csr_f32(16, 16, None, *K0, 16, 2, None, None, 32, 4, 2, 2, 4, *E0, None) == -1          # ldx < F
+    assert L.dgmi_spmm_csr_f32(16, 16, None, *K0, 64, 4, None, None, 64, 4, 2, 2, 4, *E0, None) == -1          # Y aliases X
+    assert L.dgmi_spmm_csr_f32(16, 16, None, None, 16, 1, 16, 4, None, None, 32, 4, 2, 2, 4, *E0, None) == -1  # keep without eid
+    assert L.dgmi_spmm_csr_f32(16, 16, None, 16, 16, 9, 16, 4, None, None, 32, 4, 2, 2, 4, *E0, None) == -1    # > 8 descriptions
     assert L.dgmi_random_subset_select(10, 11, 0, 0, 16, 16, 1 << 20, None) == -1                         # keep > E
     assert L.dgmi_random_subset_select(10, 5, 0, 0, 16, 16, 8, None) == -3                                # workspace too small
     assert L.dgmi_random_subset_select(10, 5, 0, 2 ** 31 - 5, 16, 16, 1 << 20, None) == -2                # offset + E overflows
@@ -77,8 +78,8 @@ def test_argument_validation_returns_codes_without_a_gpu():
     assert L.dgmi_spmm_partials_bytes(1000, 64, 341) == (15 + 15) * 344 * 4
     assert L.dgmi_spmm_partials_bytes(0, 64, 128) == 16
     assert L.dgmi_spmm_plan_build(None, -1, 0, 64, None, 0, None, ctypes.byref(need), None) == -1
-    assert L.dgmi_spmm_csr_planned_f32(16, 16, None, *K0, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 7, 16, 16, 1 << 20, None) == -1
-    assert L.dgmi_spmm_csr_planned_f32(16, 16, None, *K0, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 64, 16, 16, 0, None) == -3
+    assert L.dgmi_spmm_csr_planned_f32(16, 16, None, *K0, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 7, 16, 16, 1 << 20, *E0, None) == -1
+    assert L.dgmi_spmm_csr_planned_f32(16, 16, None, *K0, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 64, 16, 16, 0, *E0, None) == -3
     assert L.dgmi_gather_concat_f32(None, None, -1, None, 4, 4, None, 4, 4, None, 8, None) == -1
     assert L.dgmi_gather_concat_f32(16, 16, 3, 16, 4, 4, 16, 4, 4, 16, 7, None) == -1  # ldo < Fa+Fb
     assert L.dgmi_gather_concat_f32(None, None, 0, None, 4, 4, None, 4, 4, None, 8, None) == 0
@@ -95,7 +96,7 @@ def test_torch_operator_library_is_registered():
 
     assert os.path.exists(_lib.TORCH_LIB_PATH)
     for name in ("csr_from_coo", "csr_sliced_from_coo", "plan_build", "spmm_csr", "spmm_csr_raw", "spmm_csr_out",
-                 "spmm_sliced_raw", "spmm_sliced_out", "gather_f32", "gather_concat_raw", "gather_add_raw",
+                 "spmm_sliced_raw", "spmm_sliced_out", "epilogue_backward", "gather_f32", "gather_concat_raw", "gather_add_raw",
                  "random_subset_select", "random_subset_select_batch", "keep_mask"):
         assert hasattr(torch.ops.dreamgnn_mi, name), name
     schema = torch.ops.dreamgnn_mi.spmm_csr.default._schema

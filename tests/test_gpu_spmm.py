@@ -530,3 +530,53 @@ def test_batched_subset_selection_equals_single_calls(oracle, dev):
         want = oracle.random_subset_select(Es[i], keeps[i], seeds[i], offs[i])
         assert np.array_equal(d[i].cpu().numpy(), want), i
         assert torch.equal(d[i], ops.random_subset_select(Es[i], keeps[i], seeds[i], dev, e_offset=offs[i])), i
+
+
+@pytest.mark.parametrize("F", [128, 341, 64])
+@pytest.mark.parametrize("act,slope", [(1, 0.1), (1, 0.0), (0, 0.0)])
+def test_output_epilogue_in_every_kernel_form(dev, F, act, slope):
+    """f3 epilogue (`dropout(agg_act(.))`, layers.py:134-138) inside the kernel that writes Y: the
+    fused result equals activation + mask applied afterwards to the un-fused product, bit for bit,
+    for the wave-per-row, planned (incl. chunked long rows), XCD-sliced and dense forms; the backward
+    equals torch autograd of the un-fused composition."""
+    from dream_gnn_amd import ops
+
+    gen = torch.Generator().manual_seed(F + act)
+    n_dst, n_src, E = 150, 220, 9000
+    dst = torch.randint(0, n_dst, (E,), generator=gen, dtype=torch.int32)
+    dst[:1500] = 7  # a row long enough to be cut into chunks by the plan
+    dst[dst == 3] = 4  # an empty row
+    src = torch.randint(0, n_src, (E,), generator=gen, dtype=torch.int32)
+    g = ops.CSRGraph(dst.to(dev), src.to(dev), n_dst, n_src)
+    X = torch.randn(n_src, F, generator=gen).to(dev)
+    ss, ds = torch.rand(n_src, generator=gen).to(dev) + 0.5, torch.rand(n_dst, generator=gen).to(dev) + 0.5
+    mask = (torch.rand(n_dst, F, generator=gen) < 0.7).float().to(dev)
+    mscale = 1.0 / 0.7
+    epi = (act, slope, mask, mscale)
+
+    def post(y):
+        y = torch.nn.functional.leaky_relu(y, slope) if act == 1 else y
+        return y * mask * mscale
+
+    forms = {"wave-per-row": (ops.spmm_csr_raw(g.indptr, g.indices, None, X, ss, ds),
+                              ops._launch_spmm(dev, g.indptr, g.indices, None, X, ss, ds, None, None, n_dst, n_src, F, F, epi=epi)),
+             "planned": (ops.spmm_csr_raw(g.indptr, g.indices, None, X, ss, ds, plan=g.plan),
+                         ops._launch_spmm(dev, g.indptr, g.indices, None, X, ss, ds, None, g.plan, n_dst, n_src, F, F, epi=epi))}
+    if F % 4 == 0:
+        sl = ops.SlicedCSR(dst.to(dev), src.to(dev), n_dst, n_src)
+        forms["xcd-sliced"] = (sl.spmm(X, ss, ds), sl.spmm(X, ss, ds, epi=epi))
+    for name, (plain, fused) in forms.items():
+        assert torch.equal(fused, post(plain)), name
+    dense = g._dense_product(False, X, ss, ds, None, epi)
+    ref = post(forms["planned"][0])
+    assert float((dense - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # autograd
+    x1 = X.clone().requires_grad_(True)
+    y1 = ops.spmm_csr_act_dropout(g, x1, ss, ds, act, slope, mask, mscale)
+    x2 = X.clone().requires_grad_(True)
+    y2 = post(ops.spmm_csr(g, x2, ss, ds))
+    W = torch.randn(n_dst, F, generator=gen).to(dev)
+    y1.backward(W)
+    y2.backward(W)
+    assert torch.equal(y1, y2)
+    assert float((x1.grad - x2.grad).abs().max()) <= 1e-6 * float(x2.grad.abs().max())
