@@ -84,6 +84,20 @@ def balanced_row_bounds(degree: torch.Tensor, parts: int) -> torch.Tensor:
     return torch.cummax(bounds, 0)[0]
 
 
+def choose_row_bounds(degree: torch.Tensor, parts: int, tol: float = 0.01) -> torch.Tensor:
+    """Row ranges for ``parts`` ranks: EQUAL row counts when that already balances the edges to within
+    ``tol`` of the mean (uniform degrees) — equal blocks make the exchange one unpadded
+    ``all_gather_into_tensor`` straight into the result — else the nnz-balanced cut
+    (:func:`balanced_row_bounds`)."""
+    n = int(degree.shape[0])
+    if n % parts == 0 and n > 0:
+        per = degree.to(torch.int64).view(parts, n // parts).sum(1)
+        mean = float(per.sum()) / parts
+        if mean > 0 and float(per.max()) <= (1.0 + tol) * mean:
+            return torch.arange(parts + 1, dtype=torch.int64, device=degree.device) * (n // parts)
+    return balanced_row_bounds(degree, parts)
+
+
 class RowShard:
     """This rank's rows [lo, hi) of a relation: local CSR over all in-edges of those rows."""
 

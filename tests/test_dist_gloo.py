@@ -141,7 +141,14 @@ def test_direct_exchange_indexing_world4():
 
 
 def test_balanced_row_bounds_properties():
-    from dream_gnn_amd.shard import balanced_row_bounds
+    from dream_gnn_amd.shard import balanced_row_bounds, choose_row_bounds
+
+    uniform = torch.full((800,), 100) + (torch.arange(800) % 3)        # equal rows balance the edges: even blocks
+    assert choose_row_bounds(uniform, 8).tolist() == list(range(0, 801, 100))
+    skewed = torch.cat([torch.full((100,), 1000), torch.ones(700, dtype=torch.int64)])
+    b = choose_row_bounds(skewed, 8).tolist()                           # not balanced by rows: nnz cut
+    assert b == balanced_row_bounds(skewed, 8).tolist() and b != list(range(0, 801, 100))
+    assert choose_row_bounds(torch.ones(10, dtype=torch.int64), 4).tolist() == balanced_row_bounds(torch.ones(10, dtype=torch.int64), 4).tolist()
 
     deg = torch.tensor([0, 0, 10, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1])
     b = balanced_row_bounds(deg, 2).tolist()
