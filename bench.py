@@ -22,8 +22,9 @@ other reading (config 4's node set with N x the edges) is measured in the same r
 standing and reported under `edge_scaled` (`--scale edges` swaps the two).  Every rank owns a
 contiguous block of destination rows of every graph — cut by nnz (`balanced_row_bounds`) — and all
 their in-edges; each local SpMM is followed by the exchange of its row block over RCCL
-(dream_gnn_amd/shard.py: one all-gather, or the all-links batched point-to-point form — both are
-timed at start-up and the faster one is used), overlapped with the next SpMM; time = max over ranks.
+(dream_gnn_amd/shard.py: one all-gather per product by default; `DGMI_EXCHANGE=direct` selects the
+all-links batched point-to-point form, `=auto` times both at start-up and keeps the faster),
+overlapped with the next SpMM; time = max over ranks.
 
 The JSON line carries, besides the contract fields:
   roofline      dominant product (GCMC, unweighted, scaled, F=128): `achieved` = §8(d) ALGORITHMIC
@@ -417,9 +418,16 @@ def main():
         return elapsed, float(edges.item())
 
     def pick_exchange(ops):
-        """Time both exchange forms on the real node (3 steps each) and keep the faster."""
+        """The row-block exchange form.  Default: one RCCL all-gather per product (the well-trodden path;
+        blocks are equal-sized whenever equal rows balance the edges, so nothing is padded).
+        DGMI_EXCHANGE=direct: the all-links batched point-to-point form; DGMI_EXCHANGE=auto: time both
+        on this node (3 steps each) and keep the faster.  Neither could be rehearsed over RCCL here
+        (one GPU per box), so the untested form is opt-in."""
         if world == 1:
             return None, None
+        choice = os.environ.get("DGMI_EXCHANGE", "allgather")
+        if choice in ("allgather", "direct"):
+            return choice, None
         timing = {}
         for ex in ("allgather", "direct"):
             el, _ = measure(ops, 3, 1, exchange=ex)
