@@ -160,6 +160,12 @@ hipError_t random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float*
 hipError_t gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,
                       hipStream_t s);
 
+// (f4) neighbours of the k largest cosine similarities per row of a normalised (N, D) matrix (dgmi_knn.hip)
+bool knn_supported(int64_t N, int64_t D, int64_t k);
+size_t knn_workspace_bytes(int64_t N, int k);  // partial lists when the candidates are split over workgroups (small N)
+hipError_t knn_cosine_topk_f32(const float* Xn, int64_t ld, int64_t N, int64_t D, int k, int32_t* nbr, void* workspace,
+                               hipStream_t s);
+
 // Measurement probe (dgmi_probe.hip): hash-indexed whole-row gathers in the product kernels' shape.
 hipError_t probe_row_gather(const float* table, int64_t n_rows, int64_t F, int64_t groups, int64_t per_group,
                             int64_t window, int per_xcd, float* out, hipStream_t s);

@@ -335,6 +335,21 @@ Tensor epilogue_backward(const Tensor& dY, const Tensor& Y, const OptTensor& mas
   return out;
 }
 
+// (f4) (N, k) int32 neighbours of the k largest cosine similarities per row of a row-normalised matrix
+Tensor knn_cosine_topk(const Tensor& Xn, int64_t k) {
+  Dense x = dense_of(Xn, "Xn");
+  TORCH_CHECK(x.ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x.t.data_ptr()) & 15) == 0, "Xn rows must be 16-B aligned");
+  TORCH_CHECK(dgmi_knn_cosine_supported(x.rows, x.F, k) == 1, "shape not supported by the fused kNN kernel: N=", x.rows,
+              " D=", x.F, " k=", k);
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(x.t.device());
+  Tensor nbr = at::empty({x.rows, k}, x.t.options().dtype(at::kInt));
+  const size_t wbytes = dgmi_knn_cosine_workspace_bytes(x.rows, (int32_t)k);
+  Tensor ws = scratch(x.t, wbytes, kBuilder);
+  check_status(dgmi_knn_cosine_topk_f32(x.t.data_ptr<float>(), x.ld, x.rows, x.F, (int32_t)k, nbr.data_ptr<int32_t>(),
+                                        ws.data_ptr(), (size_t)ws.numel(), stream_of(x.t)), "dgmi_knn_cosine_topk_f32");
+  return nbr;
+}
+
 // `like`: any tensor on the target device (the op needs a device to allocate on)
 Tensor random_subset_select(const Tensor& like, int64_t E, int64_t keep, int64_t seed, int64_t e_offset) {
   check_dev(like, "like");
@@ -471,6 +486,7 @@ TORCH_LIBRARY(dreamgnn_mi, m) {
         "Tensor? dst_scale, int n_dst, int n_slices, Tensor(a!) out, int act=0, float slope=0., Tensor? out_mask=None, "
         "float mask_scale=1.) -> ()");
   m.def("epilogue_backward(Tensor dY, Tensor Y, Tensor? mask, int act, float slope, float mask_scale) -> Tensor");
+  m.def("knn_cosine_topk(Tensor Xn, int k) -> Tensor");
   m.def("gather_f32(Tensor values, Tensor perm) -> Tensor");
   m.def("gather_concat_raw(Tensor src, Tensor dst, Tensor A, Tensor B) -> Tensor");
   m.def("gather_add_raw(Tensor src, Tensor dst, Tensor A, Tensor B, Tensor? bias) -> Tensor");
@@ -490,6 +506,7 @@ TORCH_LIBRARY_IMPL(dreamgnn_mi, CUDA, m) {
   m.impl("spmm_sliced_raw", spmm_sliced_new);
   m.impl("spmm_sliced_out", spmm_sliced_out);
   m.impl("epilogue_backward", epilogue_backward);
+  m.impl("knn_cosine_topk", knn_cosine_topk);
   m.impl("gather_f32", gather_f32);
   m.impl("gather_concat_raw", gather_concat_raw);
   m.impl("gather_add_raw", gather_add_raw);

@@ -750,6 +750,22 @@ def gather_add(pairs: EdgePairs, A: torch.Tensor, B: torch.Tensor, bias: Optiona
 
 
 # ---------------------------------------------------------------------------------------------
+# (f4) cosine-similarity kNN — data_loader.py:312-344 without the N x N similarity matrix
+# ---------------------------------------------------------------------------------------------
+def knn_cosine_supported(N: int, D: int, k: int) -> bool:
+    """Whether the fused MFMA kNN kernel takes this shape (``dgmi_knn_cosine_supported``)."""
+    return bool(_L.dgmi_knn_cosine_supported(int(N), int(D), int(k)))
+
+
+def knn_cosine_topk(xn: torch.Tensor, k: int) -> torch.Tensor:
+    """``(N, k)`` int32 ids of the k largest cosine similarities per row of the row-normalised ``xn``
+    (self included, descending) — ``dgmi_knn_cosine_topk_f32``: fp32-MFMA similarity tiles reduced to
+    a running top-k on chip."""
+    _require_device(xn)
+    return _T.knn_cosine_topk(xn, int(k))
+
+
+# ---------------------------------------------------------------------------------------------
 # (D3) edge-dropout selection — augmentation.py:48-52, 114-118
 # ---------------------------------------------------------------------------------------------
 def random_subset_select(E: int, keep: int, seed: int, device, e_offset: int = 0) -> torch.Tensor:

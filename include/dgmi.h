@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 11
+#define DGMI_ABI_VERSION 12
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -279,6 +279,24 @@ DGMI_API int dgmi_keep_mask_f32(const uint32_t* keep, int32_t n_keep, int64_t E,
 DGMI_API int dgmi_random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask,
                                          void* workspace, size_t workspace_bytes,
                                          dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
+ * (f4) Cosine-similarity kNN: nbr[i, 0..k) = the k rows j with the largest <Xn[i], Xn[j]> (self
+ * included, as the reference's argpartition includes it), in descending order; Xn is (N, D) fp32 with
+ * L2-normalised rows and leading dimension ld.  Replaces the dense N x N similarity matrix plus
+ * `np.argpartition(-sim, k)[:, :k]` of data_loader.py:332-341 / :293: similarity tiles are computed
+ * with fp32 MFMA (exact f32 fma chains) and reduced to a running top-k on chip; nothing of size
+ * N x N is written.  Ties at the k-th value are broken arbitrarily (upstream too).
+ * dgmi_knn_cosine_supported: 1 if the shape fits the kernel (D % 8 == 0, k <= 16, k <= N, the 32-query
+ * tile + lists within LDS: D <= 1024 for k <= 4, D <= 896 for k = 16); callers fall back otherwise.
+ * workspace: dgmi_knn_cosine_workspace_bytes(N, k) bytes of device scratch (0 for large N; for small N
+ * the candidates are split over workgroups to fill the chip and the partial lists merged by a second kernel).
+ */
+DGMI_API int dgmi_knn_cosine_supported(int64_t N, int64_t D, int64_t k);
+DGMI_API size_t dgmi_knn_cosine_workspace_bytes(int64_t N, int32_t k);
+DGMI_API int dgmi_knn_cosine_topk_f32(const float* Xn, int64_t ld, int64_t N, int64_t D, int32_t k,
+                                      int32_t* nbr, void* workspace, size_t workspace_bytes,
+                                      dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
  * Measurement probe (bench.py; not part of the product path): `groups` lane groups each gather
