@@ -332,8 +332,8 @@ DGMI_API int dgmi_gather_f32(const float* in, const int32_t* perm, int64_t n, fl
 
 DGMI_API int dgmi_knn_cosine_supported(int64_t N, int64_t D, int64_t k) { return dgmi::knn_supported(N, D, k) ? 1 : 0; }
 
-DGMI_API size_t dgmi_knn_cosine_workspace_bytes(int64_t N, int32_t k) {
-  return N < 1 || k < 1 ? 0 : dgmi::knn_workspace_bytes(N, k);
+DGMI_API size_t dgmi_knn_cosine_workspace_bytes(int64_t N, int64_t D, int32_t k) {
+  return dgmi::knn_supported(N, D, k) ? dgmi::knn_workspace_bytes(N, D, k) : 0;
 }
 
 DGMI_API int dgmi_knn_cosine_topk_f32(const float* Xn, int64_t ld, int64_t N, int64_t D, int32_t k, int32_t* nbr,
@@ -343,7 +343,7 @@ DGMI_API int dgmi_knn_cosine_topk_f32(const float* Xn, int64_t ld, int64_t N, in
   if (N == 0 || k == 0) return DGMI_OK;
   if (Xn == nullptr || nbr == nullptr || ld % 4 != 0 || (reinterpret_cast<uintptr_t>(Xn) & 15)) return DGMI_ERR_INVALID_ARG;
   if (!dgmi::knn_supported(N, D, k)) return DGMI_ERR_INVALID_ARG;
-  const size_t need = dgmi::knn_workspace_bytes(N, k);
+  const size_t need = dgmi::knn_workspace_bytes(N, D, k);
   if (need > 0 && (workspace == nullptr || workspace_bytes < need)) return DGMI_ERR_WORKSPACE;
   return from_hip(dgmi::knn_cosine_topk_f32(Xn, ld, N, D, k, nbr, workspace, as_stream(stream)));
 }

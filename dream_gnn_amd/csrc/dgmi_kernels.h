@@ -162,7 +162,14 @@ hipError_t gather_f32(const float* in, const int32_t* perm, int64_t n, float* ou
 
 // (f4) neighbours of the k largest cosine similarities per row of a normalised (N, D) matrix (dgmi_knn.hip)
 bool knn_supported(int64_t N, int64_t D, int64_t k);
-size_t knn_workspace_bytes(int64_t N, int k);  // partial lists when the candidates are split over workgroups (small N)
+size_t knn_workspace_bytes(int64_t N, int64_t D, int k);  // small N: partial lists of the candidate splits; large N: the screen's buffers
+// large N (dgmi_knn_screen.hip): bf16-MFMA screen + exact fp32 rescoring; flagged tiles recomputed by the fp32 kernel
+bool knn_screen_supported(int64_t N, int64_t D, int64_t k);
+size_t knn_screen_workspace_bytes(int64_t N, int64_t D, int k);
+hipError_t knn_cosine_topk_screened(const float* Xn, int64_t ld, int64_t N, int64_t D, int k, int32_t* nbr, void* workspace,
+                                    hipStream_t s);
+hipError_t knn_cosine_topk_exact_tiles(const float* Xn, int64_t ld, int64_t N, int64_t D, int k, int32_t* nbr,
+                                       const int32_t* flags, hipStream_t s);
 hipError_t knn_cosine_topk_f32(const float* Xn, int64_t ld, int64_t N, int64_t D, int k, int32_t* nbr, void* workspace,
                                hipStream_t s);
 

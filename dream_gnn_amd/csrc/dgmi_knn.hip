@@ -51,7 +51,8 @@ __device__ __forceinline__ void topk_insert(float* __restrict__ val, int32_t* __
 __global__ __launch_bounds__(kThreads) void knn_cosine_topk_kernel(const float* __restrict__ Xn, int64_t ld, int N, int D,
                                                                    int k, int32_t* __restrict__ nbr,
                                                                    float* __restrict__ part_val,
-                                                                   int32_t* __restrict__ part_idx) {
+                                                                   int32_t* __restrict__ part_idx,
+                                                                   const int32_t* __restrict__ only_flagged) {
   extern __shared__ float knn_lds[];
   const int stride = D + kPad;
   float* q_lds = knn_lds;                                             // [kQ][D + kPad]
@@ -60,6 +61,8 @@ __global__ __launch_bounds__(kThreads) void knn_cosine_topk_kernel(const float* 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, col = lane & 31;
   const int q0 = (int)blockIdx.x * kQ;
+  // exact recomputation behind the bf16 screen (dgmi_knn_screen.hip): only tiles holding a flagged query run
+  if (only_flagged != nullptr && !__syncthreads_or(tid < kQ && q0 + tid < N && only_flagged[q0 + tid] != 0)) return;
 
   // queries -> LDS (rows past the end repeat the last row; their results are never written)
   for (int i = tid; i < kQ * (D / 4); i += kThreads) {
@@ -207,13 +210,26 @@ int knn_splits(int64_t N) {
   return (int)(s < 1 ? 1 : s);
 }
 
-size_t knn_workspace_bytes(int64_t N, int k) {
+size_t knn_workspace_bytes(int64_t N, int64_t D, int k) {
+  if (knn_screen_supported(N, D, k)) return knn_screen_workspace_bytes(N, D, k);
   const int s = knn_splits(N);
   return s == 1 ? 0 : (size_t)s * (size_t)N * (size_t)k * 8;
 }
 
+hipError_t knn_cosine_topk_exact_tiles(const float* Xn, int64_t ld, int64_t N, int64_t D, int k, int32_t* nbr,
+                                       const int32_t* flags, hipStream_t s) {
+  const size_t lds = knn_lds_bytes(D, k);
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_cosine_topk_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(knn_cosine_topk_kernel, dim3((unsigned)((N + kQ - 1) / kQ), 1), dim3(kThreads), lds, s, Xn, ld, (int)N,
+                     (int)D, k, nbr, (float*)nullptr, (int32_t*)nullptr, flags);
+  return hipGetLastError();
+}
+
 hipError_t knn_cosine_topk_f32(const float* Xn, int64_t ld, int64_t N, int64_t D, int k, int32_t* nbr, void* workspace,
                                hipStream_t s) {
+  if (knn_screen_supported(N, D, k)) return knn_cosine_topk_screened(Xn, ld, N, D, k, nbr, workspace, s);
   const size_t lds = knn_lds_bytes(D, k);
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_cosine_topk_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -223,7 +239,7 @@ hipError_t knn_cosine_topk_f32(const float* Xn, int64_t ld, int64_t N, int64_t D
   int32_t* part_idx = reinterpret_cast<int32_t*>(part_val + (size_t)splits * N * k);
   const unsigned blocks = (unsigned)((N + kQ - 1) / kQ);
   hipLaunchKernelGGL(knn_cosine_topk_kernel, dim3(blocks, (unsigned)splits), dim3(kThreads), lds, s, Xn, ld, (int)N, (int)D, k,
-                     nbr, part_val, part_idx);
+                     nbr, part_val, part_idx, (const int32_t*)nullptr);
   if (splits > 1)
     hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, part_val, part_idx, (int)N, k,
                        splits, nbr);

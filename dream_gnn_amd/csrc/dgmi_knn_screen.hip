@@ -1,0 +1,481 @@
+// dgmi_knn_screen.hip — (f4, at scale) cosine kNN for large N: bf16-MFMA screen + exact fp32 rescoring (gfx950).
+//
+// The fp32 kernel of dgmi_knn.hip runs on `v_mfma_f32_32x32x2_f32`, 1/16 of the bf16 matrix rate.  At
+// scale (reference data_loader.py:312-344 on N >> 10^4 rows) the neighbour SEARCH is done on the bf16
+// matrix cores, and the answer is still the fp32 one — by a bound, not by hope:
+//
+//   rows are L2-normalised, bf16 rounding is |d| <= 2^-9 per element, bf16 x bf16 products are exact in
+//   the fp32 accumulator, so  |approx(q, c) - <q, c>| <= (2^-8 + 2^-18) |q| |c| + fp32 summation error
+//   <= kScreenEps.  Let tau = the k-th largest approx score of query q.  k candidates have an exact
+//   score >= tau - eps, so every member of the exact top-k has exact >= tau - eps, hence
+//   approx >= tau - 2 eps.  Any lower bound tau' <= tau only enlarges that set.
+//
+// Pipeline (all on one stream, no host round trip):
+//   1. knn_to_bf16_kernel        Xn -> bf16 copy, rows / columns zero-padded to 128 / 64
+//   2. knn_screen_kernel<SAMPLE> every 8th candidate tile: each lane keeps the TWO largest approx scores of the
+//                                candidates it sees for its query (registers; 32 disjoint subsets per query)
+//      knn_tau_kernel            tau'(q) = k-th largest of those 64 scores of 64 distinct candidates: k
+//                                candidates reach it, so it is a lower bound of tau (k <= 16 < 64)
+//   3. knn_screen_kernel<EMIT>   all candidates: (id, approx) of every pair with approx >= tau' - 2 eps
+//                                appended to the query's buffer (LDS counters; order irrelevant)
+//   4. knn_rescore_kernel        one wave per query: tau from the buffer, exact fp32 dot products of the
+//                                entries >= tau - 2 eps, top-k by (score desc, id asc); a query whose
+//                                buffer overflowed is flagged
+//   5. knn_cosine_topk_kernel    (dgmi_knn.hip) recomputes the 32-query tiles holding a flagged query
+//                                exactly; every other workgroup leaves at once
+//
+// Screen kernel: workgroup = 128 queries x 128 candidates per step, K chunks of 64 bf16 staged through
+// LDS (two buffers, 16-B slots XOR-swizzled by (row >> 1) & 7: `ds_read_b128` and the staging writes
+// are conflict-free on the 64-bank array), 4 waves as 2 x 2, each wave 2 x 2 `v_mfma_f32_32x32x16_bf16`
+// tiles (A = candidates, B = queries: a lane's 16 results per tile belong to ONE query).  Block ids are
+// laid out per XCD in super-tiles of 8 query tiles x 8 candidate splits: the 64 workgroups one XCD runs
+// together share 8 query tiles (1.5 MB at D = 768, resident in its 4 MiB L2) and walk 8 candidate
+// ranges in step, so a candidate tile is fetched from HBM once per 8 query tiles.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "dgmi_kernels.h"
+
+namespace dgmi {
+namespace {
+
+constexpr int kSQ = 128;  // queries per workgroup
+constexpr int kSC = 128;  // candidates per step
+constexpr int kSK = 64;   // bf16 per K chunk (128 B per row)
+constexpr int kSplits = 8;
+constexpr int kSThreads = 256;
+constexpr int kScreenMinRows = 1536;  // measured crossover against the fp32 kernel (tools/knn_crossover.py)
+constexpr int kStageBytes = (kSQ + kSC) * kSK * 2;  // one buffer: 32 KiB
+constexpr float kScreenEps = 0.0042f;                // 2^-8 + 2^-18 + slack for fp32 accumulation / norms
+constexpr float kUnset = -2.0f;                      // below every cosine; list filler
+constexpr float kMasked = -4.0f;                     // score given to padding candidates
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void knn_to_bf16_kernel(const float* __restrict__ Xn, int64_t ld, int N, int D,
+                                                          uint16_t* __restrict__ Xb, int Np, int Dp) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = Dp / 8;
+  if (i >= (int64_t)Np * per_row) return;
+  const int row = (int)(i / per_row), c0 = (int)(i - (int64_t)row * per_row) * 8;
+  uint32_t h[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float f = row < N && c0 + j < D ? Xn[(int64_t)row * ld + c0 + j] : 0.f;
+    const uint32_t u = __float_as_uint(f);
+    h[j] = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;  // round to nearest even (inputs are finite, |x| <= 1)
+  }
+  uint4 o;
+  o.x = h[0] | (h[1] << 16);
+  o.y = h[2] | (h[3] << 16);
+  o.z = h[4] | (h[5] << 16);
+  o.w = h[6] | (h[7] << 16);
+  *reinterpret_cast<uint4*>(Xb + (int64_t)row * Dp + c0) = o;
+}
+
+struct ScreenArgs {
+  const uint16_t* Xb;  // [Np][Dp] bf16
+  int N, Np, Dp, k, cap;
+  float* part_val;     // SAMPLE: [N][kSplits][4][2] the two largest approx scores of each subset (kUnset: none)
+  const float* tau0;   // EMIT: [N] lower bound of the k-th largest approx score
+  int32_t* cnt;        // EMIT: [N][kSplits] entries offered (may exceed cap: overflow)
+  int2* buf;           // EMIT: [N][kSplits][cap] (candidate id, approx bits)
+};
+
+template <bool EMIT>
+__global__ __launch_bounds__(kSThreads, 2) void knn_screen_kernel(ScreenArgs a) {
+  extern __shared__ __align__(16) unsigned char screen_lds[];
+  unsigned char* stage = screen_lds;                                         // [2][256 rows][128 B]
+  uint32_t* cnt_sh = reinterpret_cast<uint32_t*>(screen_lds + 2 * kStageBytes);  // EMIT: [kSQ]
+
+  // block -> (query tile, candidate split): XCD x gets blocks x, x + 8, ...; 64 consecutive ones of an
+  // XCD form one super-tile (8 query tiles of query group G, 8 splits)
+  const int n_qtiles = a.Np / kSQ, n_ctiles = a.Np / kSC;
+  const int b = (int)blockIdx.x, xcd = b & 7, j = b >> 3;
+  const int inner = j & 63, G = (j >> 6) * 8 + xcd;
+  const int q_tile = G * 8 + (inner & 7), split = inner >> 3;
+  if (q_tile >= n_qtiles) return;
+
+  // candidate tiles of this workgroup: SAMPLE = every stride-th tile (stride 8; less when that would leave
+  // a split without a tile), dealt round-robin to the splits; EMIT = the split's contiguous range
+  int t0, tstep, nt;
+  if (EMIT) {
+    const int per = (n_ctiles + kSplits - 1) / kSplits;
+    t0 = split * per;
+    tstep = 1;
+    nt = t0 + per <= n_ctiles ? per : (n_ctiles > t0 ? n_ctiles - t0 : 0);
+  } else {
+    const int stride = n_ctiles >= 64 ? 8 : (n_ctiles >= 8 ? n_ctiles / 8 : 1);
+    t0 = stride * split;
+    tstep = stride * kSplits;
+    nt = n_ctiles > t0 ? (n_ctiles - t0 + tstep - 1) / tstep : 0;
+  }
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, wq = wave & 1, wc = wave >> 1;
+  const int Dp = a.Dp, nK = Dp / kSK;
+
+  // staging: thread -> 16-B slot c of rows r0 + 32 i (i < 4 candidates, i >= 4 queries)
+  const int sc = tid & 7, sr0 = tid >> 3;
+  const uint16_t* q_src = a.Xb + ((int64_t)q_tile * kSQ + sr0) * Dp + sc * 8;
+  const uint16_t* c_src0 = a.Xb + (int64_t)sr0 * Dp + sc * 8;
+  const int st_off0 = sr0 * 128 + ((sc ^ ((sr0 >> 1) & 7)) << 4);  // + 32 i rows: the swizzle term does not change
+  // fragment reads: row (tile base + r), slot (2 ks + h) ^ swizzle(r)  (tile bases are multiples of 16)
+  const int rd_row = r * 128, swz = (r >> 1) & 7;
+  int rd_slot[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) rd_slot[ks] = ((2 * ks + h) ^ swz) << 4;
+  const int a_base = (wc * 64) * 128 + rd_row, b_base = (kSC + wq * 64) * 128 + rd_row;
+
+  float max1[2] = {kUnset, kUnset}, max2[2] = {kUnset, kUnset};
+  float ethr[2] = {4.0f, 4.0f};
+  if (EMIT) {
+    if (tid < kSQ) cnt_sh[tid] = 0;
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      const int qg = q_tile * kSQ + wq * 64 + qs * 32 + r;
+      if (qg < a.N) ethr[qs] = a.tau0[qg] - 2.f * kScreenEps;
+    }
+  }
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+    for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[qs][cs][v] = 0.f;
+
+  // next chunk's 8 slots, held in registers across the MFMAs (named, not an array: an indexed array
+  // under the `more` predicate ends up in scratch)
+  uint4 g0, g1, g2, g3, g4, g5, g6, g7;
+  const int64_t rows32 = (int64_t)32 * Dp;
+#define DGMI_SCREEN_GLOAD(tile_, kc_)                                                 \
+  {                                                                                   \
+    const uint16_t* cs_ = c_src0 + (int64_t)(tile_) * kSC * Dp + (kc_) * kSK;         \
+    const uint16_t* qs_ = q_src + (kc_) * kSK;                                        \
+    g0 = *reinterpret_cast<const uint4*>(cs_);                                        \
+    g1 = *reinterpret_cast<const uint4*>(cs_ + rows32);                               \
+    g2 = *reinterpret_cast<const uint4*>(cs_ + 2 * rows32);                           \
+    g3 = *reinterpret_cast<const uint4*>(cs_ + 3 * rows32);                           \
+    g4 = *reinterpret_cast<const uint4*>(qs_);                                        \
+    g5 = *reinterpret_cast<const uint4*>(qs_ + rows32);                               \
+    g6 = *reinterpret_cast<const uint4*>(qs_ + 2 * rows32);                           \
+    g7 = *reinterpret_cast<const uint4*>(qs_ + 3 * rows32);                           \
+  }
+#define DGMI_SCREEN_LSTORE(sel_)                                                      \
+  {                                                                                   \
+    unsigned char* base_ = stage + (sel_) * kStageBytes + st_off0;                    \
+    *reinterpret_cast<uint4*>(base_) = g0;                                            \
+    *reinterpret_cast<uint4*>(base_ + 32 * 128) = g1;                                 \
+    *reinterpret_cast<uint4*>(base_ + 64 * 128) = g2;                                 \
+    *reinterpret_cast<uint4*>(base_ + 96 * 128) = g3;                                 \
+    *reinterpret_cast<uint4*>(base_ + 128 * 128) = g4;                                \
+    *reinterpret_cast<uint4*>(base_ + 160 * 128) = g5;                                \
+    *reinterpret_cast<uint4*>(base_ + 192 * 128) = g6;                                \
+    *reinterpret_cast<uint4*>(base_ + 224 * 128) = g7;                                \
+  }
+
+  const int total = nt * nK;
+  if (total > 0) {
+    DGMI_SCREEN_GLOAD(t0, 0);
+    DGMI_SCREEN_LSTORE(0);
+  }
+  __syncthreads();
+
+  int tile = t0, kc = 0;
+  for (int it = 0; it < total; ++it) {
+    int ntile = tile, nkc = kc + 1;
+    if (nkc == nK) {
+      nkc = 0;
+      ntile += tstep;
+    }
+    const bool more = it + 1 < total;
+    if (more) DGMI_SCREEN_GLOAD(ntile, nkc);
+
+    const unsigned char* base = stage + (it & 1) * kStageBytes;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int cs = 0; cs < 2; ++cs)
+        fa[cs] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + a_base + cs * 32 * 128 + rd_slot[ks]));
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs)
+        fb[qs] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + b_base + qs * 32 * 128 + rd_slot[ks]));
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int cs = 0; cs < 2; ++cs) acc[qs][cs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cs], fb[qs], acc[qs][cs], 0, 0, 0);
+    }
+
+    if (kc == nK - 1) {
+      // acc[qs][cs][v] = approx <candidate c_base + 32 cs + 8 (v >> 2) + 4 h + (v & 3), query wq 64 + 32 qs + r>
+      const int c_base = tile * kSC + wc * 64;
+      if (c_base + 64 > a.N) {  // padding candidates (last tile only)
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+          for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+              if (c_base + 32 * cs + 8 * (v >> 2) + 4 * h + (v & 3) >= a.N) acc[qs][cs][v] = kMasked;
+      }
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        float mx = kMasked;
+#pragma unroll
+        for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) mx = fmaxf(mx, acc[qs][cs][v]);
+        if (EMIT) {
+          if (mx >= ethr[qs]) {
+            const int ql = wq * 64 + qs * 32 + r;
+            const int64_t row = ((int64_t)(q_tile * kSQ + ql) * kSplits + split) * a.cap;
+#pragma unroll
+            for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+              for (int v = 0; v < 16; ++v) {
+                const float s = acc[qs][cs][v];
+                if (s >= ethr[qs]) {
+                  const uint32_t slot = atomicAdd(&cnt_sh[ql], 1u);
+                  if (slot < (uint32_t)a.cap)
+                    a.buf[row + slot] = make_int2(c_base + 32 * cs + 8 * (v >> 2) + 4 * h + (v & 3), __float_as_int(s));
+                }
+              }
+          }
+        } else if (mx > max2[qs]) {
+#pragma unroll
+          for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+              const float s = acc[qs][cs][v];
+              max2[qs] = fmaxf(max2[qs], fminf(max1[qs], s));  // branch-free top-2 update
+              max1[qs] = fmaxf(max1[qs], s);
+            }
+        }
+      }
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[qs][cs][v] = 0.f;
+    }
+
+    if (more) DGMI_SCREEN_LSTORE((it + 1) & 1);
+    __syncthreads();
+    tile = ntile;
+    kc = nkc;
+  }
+
+  if (EMIT) {
+    if (tid < kSQ && q_tile * kSQ + tid < a.N) a.cnt[(int64_t)(q_tile * kSQ + tid) * kSplits + split] = (int32_t)cnt_sh[tid];
+  } else {
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      const int qg = q_tile * kSQ + wq * 64 + qs * 32 + r;
+      if (qg < a.N)
+        *reinterpret_cast<float2*>(a.part_val + (((int64_t)qg * kSplits + split) * 4 + (wc * 2 + h)) * 2) =
+            make_float2(max1[qs], max2[qs]);
+    }
+  }
+}
+
+#undef DGMI_SCREEN_GLOAD
+#undef DGMI_SCREEN_LSTORE
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// k-th largest of the values v[0..J) held per lane across the wave (destroys v)
+template <int J>
+__device__ __forceinline__ float wave_kth_largest(float (&v)[J], int k, int lane) {
+  float m = kUnset;
+  for (int round = 0; round < k; ++round) {
+    float lm = kMasked;
+#pragma unroll
+    for (int i = 0; i < J; ++i) lm = fmaxf(lm, v[i]);
+    m = wave_max(lm);
+    const uint64_t holders = __ballot(lm == m);
+    if (lane == __ffsll((long long)holders) - 1) {  // the first holder drops ONE instance
+      bool done = false;
+#pragma unroll
+      for (int i = 0; i < J; ++i)
+        if (!done && v[i] == m) {
+          v[i] = kMasked;
+          done = true;
+        }
+    }
+  }
+  return m;
+}
+
+// tau0[q] = k-th largest of the 64 sample scores (top two of 32 subsets) of query q (one wave per query)
+__global__ __launch_bounds__(256) void knn_tau_kernel(const float* __restrict__ part_val, int N, int k, float* __restrict__ tau0) {
+  const int lane = threadIdx.x & 63, q = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= N) return;
+  float v[1] = {part_val[(int64_t)q * kSplits * 8 + lane]};
+  const float t = wave_kth_largest<1>(v, k, lane);
+  if (lane == 0) tau0[q] = t;
+}
+
+// One wave per query: exact top-k among the screened candidates.  kJ = entries per lane (8 cap / 64).
+template <int kJ>
+__global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restrict__ Xn, int64_t ld, int N, int D, int k, int cap,
+                                                          const int32_t* __restrict__ cnt, const int2* __restrict__ buf,
+                                                          int32_t* __restrict__ nbr, int32_t* __restrict__ flags) {
+  const int lane = threadIdx.x & 63, q = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= N) return;
+  // entries: slot e = lane + 64 i of the query's [kSplits][cap] buffer
+  int32_t e_id[kJ];
+  float e_s[kJ], work[kJ];
+  bool over = false;
+#pragma unroll
+  for (int i = 0; i < kJ; ++i) {
+    const int e = lane + 64 * i, sp = e / cap, at = e - sp * cap;
+    const int c = cnt[(int64_t)q * kSplits + sp];
+    over |= c > cap;
+    const bool live = at < c;
+    const int2 rec = live ? buf[((int64_t)q * kSplits + sp) * cap + at] : make_int2(-1, 0);
+    e_id[i] = rec.x;
+    e_s[i] = live ? __int_as_float(rec.y) : kMasked;
+    work[i] = e_s[i];
+  }
+  if (__ballot(over) != 0) {  // a buffer overflowed: the 32-query tile is recomputed exactly afterwards
+    if (lane == 0) flags[q] = 1;
+    return;
+  }
+  if (lane == 0) flags[q] = 0;
+  const float tau = wave_kth_largest<kJ>(work, k, lane);
+  const float keep_from = tau - 2.f * kScreenEps;
+
+  // the query row, 16 B per lane per 256 columns
+  const int d4 = D / 4;
+  const float4* qrow = reinterpret_cast<const float4*>(Xn + (int64_t)q * ld);
+  float4 qv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qv[i] = lane + 64 * i < d4 ? qrow[lane + 64 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+
+  float best_s = kMasked;  // lane i < k: the i-th best (score desc, id asc)
+  int32_t best_id = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < kJ; ++i) {
+    uint64_t todo = __ballot(e_s[i] >= keep_from);
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int32_t cid = __shfl(e_id[i], src);
+      const float4* crow = reinterpret_cast<const float4*>(Xn + (int64_t)cid * ld);
+      float s = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < d4) {
+          const float4 c = crow[lane + 64 * u];
+          s = fmaf(qv[u].x, c.x, s);
+          s = fmaf(qv[u].y, c.y, s);
+          s = fmaf(qv[u].z, c.z, s);
+          s = fmaf(qv[u].w, c.w, s);
+        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);  // fixed tree: the same sum on every lane
+      const bool better = best_s > s || (best_s == s && best_id < cid);
+      const int pos = __popcll(__ballot(better && lane < k));
+      const float up_s = __shfl_up(best_s, 1);
+      const int32_t up_id = __shfl_up(best_id, 1);
+      if (lane < k && lane > pos) {
+        best_s = up_s;
+        best_id = up_id;
+      } else if (lane == pos && pos < k) {
+        best_s = s;
+        best_id = cid;
+      }
+    }
+  }
+  if (lane < k) nbr[(int64_t)q * k + lane] = best_id;
+}
+
+inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct ScreenLayout {
+  int Np, Dp, cap;
+  size_t xb, part, tau, cnt, buf, flags, total;
+};
+
+ScreenLayout screen_layout(int64_t N, int64_t D, int k) {
+  ScreenLayout L;
+  L.Np = (int)((N + kSQ - 1) / kSQ * kSQ);
+  L.Dp = (int)((D + kSK - 1) / kSK * kSK);
+  L.cap = k <= 8 ? 64 : 128;
+  size_t at = 0;
+  L.xb = at, at += align256((size_t)L.Np * L.Dp * 2);
+  L.part = at, at += align256((size_t)N * kSplits * 8 * 4);
+  L.tau = at, at += align256((size_t)N * 4);
+  L.cnt = at, at += align256((size_t)N * kSplits * 4);
+  L.buf = at, at += align256((size_t)N * kSplits * L.cap * 8);
+  L.flags = at, at += align256((size_t)N * 4);
+  L.total = at;
+  return L;
+}
+
+}  // namespace
+
+bool knn_screen_supported(int64_t N, int64_t D, int64_t k) {
+  // the rescoring holds a row in 4 float4 per lane; below kScreenMinRows the fp32 kernel alone is faster
+  // (DGMI_KNN_SCREEN_MIN_ROWS overrides the crossover, for tools/knn_bench.py)
+  static const int64_t min_rows = [] {
+    const char* e = getenv("DGMI_KNN_SCREEN_MIN_ROWS");
+    const long long v = e != nullptr ? atoll(e) : 0;
+    return (int64_t)(v > 0 ? v : kScreenMinRows);
+  }();
+  return knn_supported(N, D, k) && N >= min_rows && N < (1 << 30) && D <= 1024;
+}
+
+size_t knn_screen_workspace_bytes(int64_t N, int64_t D, int k) { return screen_layout(N, D, k).total; }
+
+hipError_t knn_cosine_topk_screened(const float* Xn, int64_t ld, int64_t N, int64_t D, int k, int32_t* nbr, void* workspace,
+                                    hipStream_t s) {
+  const ScreenLayout L = screen_layout(N, D, k);
+  unsigned char* ws = static_cast<unsigned char*>(workspace);
+  uint16_t* Xb = reinterpret_cast<uint16_t*>(ws + L.xb);
+  float* part = reinterpret_cast<float*>(ws + L.part);
+  float* tau0 = reinterpret_cast<float*>(ws + L.tau);
+  int32_t* cnt = reinterpret_cast<int32_t*>(ws + L.cnt);
+  int2* buf = reinterpret_cast<int2*>(ws + L.buf);
+  int32_t* flags = reinterpret_cast<int32_t*>(ws + L.flags);
+
+  const int64_t n8 = (int64_t)L.Np * (L.Dp / 8);
+  hipLaunchKernelGGL(knn_to_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, Xn, ld, (int)N, (int)D, Xb, L.Np,
+                     L.Dp);
+
+  ScreenArgs a;
+  a.Xb = Xb, a.N = (int)N, a.Np = L.Np, a.Dp = L.Dp, a.k = k, a.cap = L.cap;
+  a.part_val = part, a.tau0 = tau0, a.cnt = cnt, a.buf = buf;
+  const int n_groups = (L.Np / kSQ + 7) / 8;
+  const unsigned blocks = (unsigned)(8 * ((n_groups + 7) / 8) * 64);
+  const size_t lds_lists = 2 * kStageBytes, lds_emit = 2 * kStageBytes + kSQ * 4;
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lists);
+  if (err != hipSuccess) return err;
+  err = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_emit);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(knn_screen_kernel<false>, dim3(blocks), dim3(kSThreads), lds_lists, s, a);
+  hipLaunchKernelGGL(knn_tau_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, part, (int)N, k, tau0);
+  hipLaunchKernelGGL(knn_screen_kernel<true>, dim3(blocks), dim3(kSThreads), lds_emit, s, a);
+  const dim3 rgrid((unsigned)((N + 3) / 4));
+  if (L.cap == 64)
+    hipLaunchKernelGGL(knn_rescore_kernel<8>, rgrid, dim3(256), 0, s, Xn, ld, (int)N, (int)D, k, L.cap, cnt, buf, nbr, flags);
+  else
+    hipLaunchKernelGGL(knn_rescore_kernel<16>, rgrid, dim3(256), 0, s, Xn, ld, (int)N, (int)D, k, L.cap, cnt, buf, nbr, flags);
+  err = hipGetLastError();
+  if (err != hipSuccess) return err;
+  return knn_cosine_topk_exact_tiles(Xn, ld, N, D, k, nbr, flags, s);
+}
+
+}  // namespace dgmi

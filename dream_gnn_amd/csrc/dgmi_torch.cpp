@@ -343,7 +343,7 @@ Tensor knn_cosine_topk(const Tensor& Xn, int64_t k) {
               " D=", x.F, " k=", k);
   c10::hip::HIPGuardMasqueradingAsCUDA guard(x.t.device());
   Tensor nbr = at::empty({x.rows, k}, x.t.options().dtype(at::kInt));
-  const size_t wbytes = dgmi_knn_cosine_workspace_bytes(x.rows, (int32_t)k);
+  const size_t wbytes = dgmi_knn_cosine_workspace_bytes(x.rows, x.F, (int32_t)k);
   Tensor ws = scratch(x.t, wbytes, kBuilder);
   check_status(dgmi_knn_cosine_topk_f32(x.t.data_ptr<float>(), x.ld, x.rows, x.F, (int32_t)k, nbr.data_ptr<int32_t>(),
                                         ws.data_ptr(), (size_t)ws.numel(), stream_of(x.t)), "dgmi_knn_cosine_topk_f32");

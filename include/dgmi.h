@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 12
+#define DGMI_ABI_VERSION 13
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -286,14 +286,17 @@ DGMI_API int dgmi_random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed,
  * L2-normalised rows and leading dimension ld.  Replaces the dense N x N similarity matrix plus
  * `np.argpartition(-sim, k)[:, :k]` of data_loader.py:332-341 / :293: similarity tiles are computed
  * with fp32 MFMA (exact f32 fma chains) and reduced to a running top-k on chip; nothing of size
- * N x N is written.  Ties at the k-th value are broken arbitrarily (upstream too).
+ * N x N is written.  From N = 1536 rows the candidates are first screened on the bf16 matrix cores
+ * with a rounding bound that provably keeps every member of the fp32 top-k, then rescored in fp32
+ * (rows must be unit vectors or zero for that bound).  Ties at the k-th value are broken arbitrarily
+ * (upstream too).
  * dgmi_knn_cosine_supported: 1 if the shape fits the kernel (D % 8 == 0, k <= 16, k <= N, the 32-query
  * tile + lists within LDS: D <= 1024 for k <= 4, D <= 896 for k = 16); callers fall back otherwise.
- * workspace: dgmi_knn_cosine_workspace_bytes(N, k) bytes of device scratch (0 for large N; for small N
- * the candidates are split over workgroups to fill the chip and the partial lists merged by a second kernel).
+ * workspace: dgmi_knn_cosine_workspace_bytes(N, D, k) bytes of device scratch (small N: partial lists of the
+ * candidate splits; N >= 1536: the bf16 copy + 4 KiB (k <= 8) or 8 KiB of screened candidates per row).
  */
 DGMI_API int dgmi_knn_cosine_supported(int64_t N, int64_t D, int64_t k);
-DGMI_API size_t dgmi_knn_cosine_workspace_bytes(int64_t N, int32_t k);
+DGMI_API size_t dgmi_knn_cosine_workspace_bytes(int64_t N, int64_t D, int32_t k);
 DGMI_API int dgmi_knn_cosine_topk_f32(const float* Xn, int64_t ld, int64_t N, int64_t D, int32_t k,
                                       int32_t* nbr, void* workspace, size_t workspace_bytes,
                                       dgmi_stream_t stream);

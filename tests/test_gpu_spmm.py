@@ -583,7 +583,7 @@ def test_output_epilogue_in_every_kernel_form(dev, F, act, slope):
 
 
 @pytest.mark.parametrize("N,D,k", [(763, 768, 4), (681, 768, 4), (33, 8, 1), (1000, 64, 16), (5000, 768, 8), (32, 1024, 3),
-                                   (97, 24, 13), (16500, 16, 5)])
+                                   (97, 24, 13), (1536, 64, 16), (16500, 16, 5), (20000, 768, 4), (9001, 200, 16)])
 def test_fused_knn_kernel_finds_the_k_most_similar_rows(dev, N, D, k):
     """(f4) `dgmi_knn_cosine_topk_f32` (fp32 MFMA tiles + running top-k on chip) against a brute-force
     float64 similarity matrix: every row's selected neighbours are k distinct valid ids whose
@@ -595,7 +595,8 @@ def test_fused_knn_kernel_finds_the_k_most_similar_rows(dev, N, D, k):
     X[3] = X[2] * 2.0  # an exact duplicate direction: similarity 1 with another row
     xn = (X / X.norm(dim=1, keepdim=True)).to(dev)
     assert ops.knn_cosine_supported(N, D, k)
-    nbr = ops.knn_cosine_topk(xn, k).long()  # 763: candidates split over workgroups + merge; 16500: one pass
+    # N < 1536: fp32 kernel, candidates split over workgroups + merge; above: bf16 screen + exact rescoring
+    nbr = ops.knn_cosine_topk(xn, k).long()
     sim = xn.double() @ xn.double().t()
     assert nbr.shape == (N, k) and int(nbr.min()) >= 0 and int(nbr.max()) < N
     assert all(len(set(r.tolist())) == k for r in nbr)  # distinct
@@ -614,3 +615,22 @@ def test_fused_knn_kernel_finds_the_k_most_similar_rows(dev, N, D, k):
         assert torch.equal(a.values(), b.values())
     else:  # near-ties picked differently: the graphs still have the same size up to those rows
         assert abs(a._nnz() - b._nnz()) <= 4
+
+
+def test_screened_knn_recomputes_overflowing_rows_exactly(dev):
+    """(f4) the bf16 screen keeps at most 64 candidates per (query, candidate split); a cluster of 400
+    near-identical rows puts far more than that within the 2-eps margin of the k-th best, so those queries
+    are flagged and their tiles recomputed by the fp32 kernel — the answer is still the exact top-k."""
+    from dream_gnn_amd import ops
+
+    N, D, k = 10000, 128, 4
+    gen = torch.Generator().manual_seed(5)
+    X = torch.randn(N, D, generator=gen)
+    X[3000:3400] = X[3000] + 1e-3 * torch.randn(400, D, generator=gen)
+    xn = (X / X.norm(dim=1, keepdim=True)).to(dev)
+    nbr = ops.knn_cosine_topk(xn, k).long()
+    sim = xn.double() @ xn.double().t()
+    got = torch.gather(sim, 1, nbr)
+    want = torch.topk(sim, k, dim=1).values
+    assert float((got - want).abs().max()) <= 2e-6
+    assert all(len(set(r.tolist())) == k for r in nbr[2990:3410].cpu())
