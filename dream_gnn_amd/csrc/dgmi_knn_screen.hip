@@ -40,13 +40,24 @@
 namespace dgmi {
 namespace {
 
-constexpr int kSQ = 128;  // queries per workgroup
-constexpr int kSC = 128;  // candidates per step
+// Tile shapes.  BIG = false: 128 queries x 128 candidates per step, 4 waves as 2 (q) x 2 (c), two workgroups
+// per CU.  BIG = true (large N): 256 x 256, 8 waves as 2 (q) x 4 (c), each wave 4 x 2 MFMA tiles — half the
+// L2 -> LDS bytes per flop (the 128 x 128 shape staged 270 GB at N = 100 000: 12 ms at the 22 TB/s L2 rate,
+// against 12.7 ms of MFMA + LDS-read time, and the two overlapped poorly).
+template <bool BIG>
+struct Shape {
+  static constexpr int kWC = BIG ? 4 : 2;              // waves along the candidates
+  static constexpr int kQS = BIG ? 4 : 2;              // 32-query sub-tiles per wave
+  static constexpr int kTile = BIG ? 256 : 128;        // queries per workgroup = candidates per step
+  static constexpr int kThreads = 64 * 2 * kWC;        // 256 / 512
+  static constexpr int kRowStep = kThreads / 8;        // rows one staging instruction covers: 32 / 64
+  static constexpr int kStage = 2 * kTile * 128;       // bytes of one LDS buffer (candidate + query rows x 128 B)
+  static constexpr int kSubsets = 8 * kWC * 2;         // disjoint candidate subsets per query in the sample: 32 / 64
+};
 constexpr int kSK = 64;   // bf16 per K chunk (128 B per row)
 constexpr int kSplits = 8;
-constexpr int kSThreads = 256;
+constexpr int kScreenBigMinRows = 49152;  // 256 x 256 tiles: slower at 20 000 rows (1.34 vs 1.17 ms), 10 % faster at 100 000
 constexpr int kScreenMinRows = 1536;  // measured crossover against the fp32 kernel (tools/knn_crossover.py)
-constexpr int kStageBytes = (kSQ + kSC) * kSK * 2;  // one buffer: 32 KiB
 constexpr float kScreenEps = 0.0042f;                // 2^-8 + 2^-18 + slack for fp32 accumulation / norms
 constexpr float kUnset = -2.0f;                      // below every cosine; list filler
 constexpr float kMasked = -4.0f;                     // score given to padding candidates
@@ -77,72 +88,76 @@ __global__ __launch_bounds__(256) void knn_to_bf16_kernel(const float* __restric
 
 struct ScreenArgs {
   const uint16_t* Xb;  // [Np][Dp] bf16
-  int N, Np, Dp, k, cap;
-  float* part_val;     // SAMPLE: [N][kSplits][4][2] the two largest approx scores of each subset (kUnset: none)
+  int N, Np, Dp, k, cap;  // Np: N rounded up to the tile
+  float* part_val;     // SAMPLE: [N][subsets][2] the two largest approx scores of each subset (kUnset: none)
   const float* tau0;   // EMIT: [N] lower bound of the k-th largest approx score
   int32_t* cnt;        // EMIT: [N][kSplits] entries offered (may exceed cap: overflow)
   int2* buf;           // EMIT: [N][kSplits][cap] (candidate id, approx bits)
 };
 
-template <bool EMIT>
-__global__ __launch_bounds__(kSThreads, 2) void knn_screen_kernel(ScreenArgs a) {
+template <bool EMIT, bool BIG>
+__global__ __launch_bounds__(Shape<BIG>::kThreads, 2) void knn_screen_kernel(ScreenArgs a) {
+  using S = Shape<BIG>;
+  constexpr int QS = S::kQS, kT = S::kTile, kStageBytes = S::kStage;
   extern __shared__ __align__(16) unsigned char screen_lds[];
-  unsigned char* stage = screen_lds;                                         // [2][256 rows][128 B]
-  uint32_t* cnt_sh = reinterpret_cast<uint32_t*>(screen_lds + 2 * kStageBytes);  // EMIT: [kSQ]
+  unsigned char* stage = screen_lds;                                             // [2][2 kT rows][128 B]
+  uint32_t* cnt_sh = reinterpret_cast<uint32_t*>(screen_lds + 2 * kStageBytes);  // EMIT: [kT]
 
   // block -> (query tile, candidate split): XCD x gets blocks x, x + 8, ...; 64 consecutive ones of an
   // XCD form one super-tile (8 query tiles of query group G, 8 splits)
-  const int n_qtiles = a.Np / kSQ, n_ctiles = a.Np / kSC;
+  const int n_tiles = a.Np / kT;
   const int b = (int)blockIdx.x, xcd = b & 7, j = b >> 3;
   const int inner = j & 63, G = (j >> 6) * 8 + xcd;
   const int q_tile = G * 8 + (inner & 7), split = inner >> 3;
-  if (q_tile >= n_qtiles) return;
+  if (q_tile >= n_tiles) return;
 
   // candidate tiles of this workgroup: SAMPLE = every stride-th tile (stride 8; less when that would leave
   // a split without a tile), dealt round-robin to the splits; EMIT = the split's contiguous range
   int t0, tstep, nt;
   if (EMIT) {
-    const int per = (n_ctiles + kSplits - 1) / kSplits;
+    const int per = (n_tiles + kSplits - 1) / kSplits;
     t0 = split * per;
     tstep = 1;
-    nt = t0 + per <= n_ctiles ? per : (n_ctiles > t0 ? n_ctiles - t0 : 0);
+    nt = t0 + per <= n_tiles ? per : (n_tiles > t0 ? n_tiles - t0 : 0);
   } else {
-    const int stride = n_ctiles >= 64 ? 8 : (n_ctiles >= 8 ? n_ctiles / 8 : 1);
+    const int stride = n_tiles >= 64 ? 8 : (n_tiles >= 8 ? n_tiles / 8 : 1);
     t0 = stride * split;
     tstep = stride * kSplits;
-    nt = n_ctiles > t0 ? (n_ctiles - t0 + tstep - 1) / tstep : 0;
+    nt = n_tiles > t0 ? (n_tiles - t0 + tstep - 1) / tstep : 0;
   }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5, wq = wave & 1, wc = wave >> 1;
   const int Dp = a.Dp, nK = Dp / kSK;
+  const int q_wave = q_tile * kT + wq * (32 * QS);  // first query of this wave
 
-  // staging: thread -> 16-B slot c of rows r0 + 32 i (i < 4 candidates, i >= 4 queries)
+  // staging: thread -> 16-B slot sc of rows sr0 + kRowStep i (i < 4 candidates, i >= 4 queries)
   const int sc = tid & 7, sr0 = tid >> 3;
-  const uint16_t* q_src = a.Xb + ((int64_t)q_tile * kSQ + sr0) * Dp + sc * 8;
+  const uint16_t* q_src = a.Xb + ((int64_t)q_tile * kT + sr0) * Dp + sc * 8;
   const uint16_t* c_src0 = a.Xb + (int64_t)sr0 * Dp + sc * 8;
-  const int st_off0 = sr0 * 128 + ((sc ^ ((sr0 >> 1) & 7)) << 4);  // + 32 i rows: the swizzle term does not change
+  const int st_off0 = sr0 * 128 + ((sc ^ ((sr0 >> 1) & 7)) << 4);  // + kRowStep i rows: the swizzle term does not change
   // fragment reads: row (tile base + r), slot (2 ks + h) ^ swizzle(r)  (tile bases are multiples of 16)
   const int rd_row = r * 128, swz = (r >> 1) & 7;
   int rd_slot[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) rd_slot[ks] = ((2 * ks + h) ^ swz) << 4;
-  const int a_base = (wc * 64) * 128 + rd_row, b_base = (kSC + wq * 64) * 128 + rd_row;
+  const int a_base = (wc * 64) * 128 + rd_row, b_base = (kT + wq * 32 * QS) * 128 + rd_row;
 
-  float max1[2] = {kUnset, kUnset}, max2[2] = {kUnset, kUnset};
-  float ethr[2] = {4.0f, 4.0f};
-  if (EMIT) {
-    if (tid < kSQ) cnt_sh[tid] = 0;
+  float max1[QS], max2[QS], ethr[QS];
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
-      const int qg = q_tile * kSQ + wq * 64 + qs * 32 + r;
+  for (int qs = 0; qs < QS; ++qs) max1[qs] = max2[qs] = kUnset, ethr[qs] = 4.0f;
+  if (EMIT) {
+    if (tid < kT) cnt_sh[tid] = 0;
+#pragma unroll
+    for (int qs = 0; qs < QS; ++qs) {
+      const int qg = q_wave + qs * 32 + r;
       if (qg < a.N) ethr[qs] = a.tau0[qg] - 2.f * kScreenEps;
     }
   }
 
-  floatx16 acc[2][2];
+  floatx16 acc[QS][2];
 #pragma unroll
-  for (int qs = 0; qs < 2; ++qs)
+  for (int qs = 0; qs < QS; ++qs)
 #pragma unroll
     for (int cs = 0; cs < 2; ++cs)
 #pragma unroll
@@ -151,31 +166,32 @@ __global__ __launch_bounds__(kSThreads, 2) void knn_screen_kernel(ScreenArgs a) 
   // next chunk's 8 slots, held in registers across the MFMAs (named, not an array: an indexed array
   // under the `more` predicate ends up in scratch)
   uint4 g0, g1, g2, g3, g4, g5, g6, g7;
-  const int64_t rows32 = (int64_t)32 * Dp;
+  const int64_t rstep = (int64_t)S::kRowStep * Dp;
 #define DGMI_SCREEN_GLOAD(tile_, kc_)                                                 \
   {                                                                                   \
-    const uint16_t* cs_ = c_src0 + (int64_t)(tile_) * kSC * Dp + (kc_) * kSK;         \
+    const uint16_t* cs_ = c_src0 + (int64_t)(tile_) * kT * Dp + (kc_) * kSK;          \
     const uint16_t* qs_ = q_src + (kc_) * kSK;                                        \
     g0 = *reinterpret_cast<const uint4*>(cs_);                                        \
-    g1 = *reinterpret_cast<const uint4*>(cs_ + rows32);                               \
-    g2 = *reinterpret_cast<const uint4*>(cs_ + 2 * rows32);                           \
-    g3 = *reinterpret_cast<const uint4*>(cs_ + 3 * rows32);                           \
+    g1 = *reinterpret_cast<const uint4*>(cs_ + rstep);                                \
+    g2 = *reinterpret_cast<const uint4*>(cs_ + 2 * rstep);                            \
+    g3 = *reinterpret_cast<const uint4*>(cs_ + 3 * rstep);                            \
     g4 = *reinterpret_cast<const uint4*>(qs_);                                        \
-    g5 = *reinterpret_cast<const uint4*>(qs_ + rows32);                               \
-    g6 = *reinterpret_cast<const uint4*>(qs_ + 2 * rows32);                           \
-    g7 = *reinterpret_cast<const uint4*>(qs_ + 3 * rows32);                           \
+    g5 = *reinterpret_cast<const uint4*>(qs_ + rstep);                                \
+    g6 = *reinterpret_cast<const uint4*>(qs_ + 2 * rstep);                            \
+    g7 = *reinterpret_cast<const uint4*>(qs_ + 3 * rstep);                            \
   }
 #define DGMI_SCREEN_LSTORE(sel_)                                                      \
   {                                                                                   \
     unsigned char* base_ = stage + (sel_) * kStageBytes + st_off0;                    \
+    constexpr int rs_ = S::kRowStep * 128;                                            \
     *reinterpret_cast<uint4*>(base_) = g0;                                            \
-    *reinterpret_cast<uint4*>(base_ + 32 * 128) = g1;                                 \
-    *reinterpret_cast<uint4*>(base_ + 64 * 128) = g2;                                 \
-    *reinterpret_cast<uint4*>(base_ + 96 * 128) = g3;                                 \
-    *reinterpret_cast<uint4*>(base_ + 128 * 128) = g4;                                \
-    *reinterpret_cast<uint4*>(base_ + 160 * 128) = g5;                                \
-    *reinterpret_cast<uint4*>(base_ + 192 * 128) = g6;                                \
-    *reinterpret_cast<uint4*>(base_ + 224 * 128) = g7;                                \
+    *reinterpret_cast<uint4*>(base_ + rs_) = g1;                                      \
+    *reinterpret_cast<uint4*>(base_ + 2 * rs_) = g2;                                  \
+    *reinterpret_cast<uint4*>(base_ + 3 * rs_) = g3;                                  \
+    *reinterpret_cast<uint4*>(base_ + 4 * rs_) = g4;                                  \
+    *reinterpret_cast<uint4*>(base_ + 5 * rs_) = g5;                                  \
+    *reinterpret_cast<uint4*>(base_ + 6 * rs_) = g6;                                  \
+    *reinterpret_cast<uint4*>(base_ + 7 * rs_) = g7;                                  \
   }
 
   const int total = nt * nK;
@@ -198,25 +214,25 @@ __global__ __launch_bounds__(kSThreads, 2) void knn_screen_kernel(ScreenArgs a) 
     const unsigned char* base = stage + (it & 1) * kStageBytes;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 fa[2], fb[2];
+      bf16x8 fa[2], fb[QS];
 #pragma unroll
       for (int cs = 0; cs < 2; ++cs)
         fa[cs] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + a_base + cs * 32 * 128 + rd_slot[ks]));
 #pragma unroll
-      for (int qs = 0; qs < 2; ++qs)
+      for (int qs = 0; qs < QS; ++qs)
         fb[qs] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(base + b_base + qs * 32 * 128 + rd_slot[ks]));
 #pragma unroll
-      for (int qs = 0; qs < 2; ++qs)
+      for (int qs = 0; qs < QS; ++qs)
 #pragma unroll
         for (int cs = 0; cs < 2; ++cs) acc[qs][cs] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cs], fb[qs], acc[qs][cs], 0, 0, 0);
     }
 
     if (kc == nK - 1) {
-      // acc[qs][cs][v] = approx <candidate c_base + 32 cs + 8 (v >> 2) + 4 h + (v & 3), query wq 64 + 32 qs + r>
-      const int c_base = tile * kSC + wc * 64;
+      // acc[qs][cs][v] = approx <candidate c_base + 32 cs + 8 (v >> 2) + 4 h + (v & 3), query q_wave + 32 qs + r>
+      const int c_base = tile * kT + wc * 64;
       if (c_base + 64 > a.N) {  // padding candidates (last tile only)
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs)
+        for (int qs = 0; qs < QS; ++qs)
 #pragma unroll
           for (int cs = 0; cs < 2; ++cs)
 #pragma unroll
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(kSThreads, 2) void knn_screen_kernel(ScreenArgs a) 
               if (c_base + 32 * cs + 8 * (v >> 2) + 4 * h + (v & 3) >= a.N) acc[qs][cs][v] = kMasked;
       }
 #pragma unroll
-      for (int qs = 0; qs < 2; ++qs) {
+      for (int qs = 0; qs < QS; ++qs) {
         float mx = kMasked;
 #pragma unroll
         for (int cs = 0; cs < 2; ++cs)
@@ -232,8 +248,8 @@ __global__ __launch_bounds__(kSThreads, 2) void knn_screen_kernel(ScreenArgs a) 
           for (int v = 0; v < 16; ++v) mx = fmaxf(mx, acc[qs][cs][v]);
         if (EMIT) {
           if (mx >= ethr[qs]) {
-            const int ql = wq * 64 + qs * 32 + r;
-            const int64_t row = ((int64_t)(q_tile * kSQ + ql) * kSplits + split) * a.cap;
+            const int ql = wq * (32 * QS) + qs * 32 + r;
+            const int64_t row = ((int64_t)(q_tile * kT + ql) * kSplits + split) * a.cap;
 #pragma unroll
             for (int cs = 0; cs < 2; ++cs)
 #pragma unroll
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(kSThreads, 2) void knn_screen_kernel(ScreenArgs a) 
         }
       }
 #pragma unroll
-      for (int qs = 0; qs < 2; ++qs)
+      for (int qs = 0; qs < QS; ++qs)
 #pragma unroll
         for (int cs = 0; cs < 2; ++cs)
 #pragma unroll
@@ -272,13 +288,13 @@ __global__ __launch_bounds__(kSThreads, 2) void knn_screen_kernel(ScreenArgs a) 
   }
 
   if (EMIT) {
-    if (tid < kSQ && q_tile * kSQ + tid < a.N) a.cnt[(int64_t)(q_tile * kSQ + tid) * kSplits + split] = (int32_t)cnt_sh[tid];
+    if (tid < kT && q_tile * kT + tid < a.N) a.cnt[(int64_t)(q_tile * kT + tid) * kSplits + split] = (int32_t)cnt_sh[tid];
   } else {
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
-      const int qg = q_tile * kSQ + wq * 64 + qs * 32 + r;
+    for (int qs = 0; qs < QS; ++qs) {
+      const int qg = q_wave + qs * 32 + r;
       if (qg < a.N)
-        *reinterpret_cast<float2*>(a.part_val + (((int64_t)qg * kSplits + split) * 4 + (wc * 2 + h)) * 2) =
+        *reinterpret_cast<float2*>(a.part_val + ((int64_t)qg * S::kSubsets + (split * S::kWC + wc) * 2 + h) * 2) =
             make_float2(max1[qs], max2[qs]);
     }
   }
@@ -316,12 +332,15 @@ __device__ __forceinline__ float wave_kth_largest(float (&v)[J], int k, int lane
   return m;
 }
 
-// tau0[q] = k-th largest of the 64 sample scores (top two of 32 subsets) of query q (one wave per query)
+// tau0[q] = k-th largest of the sample scores (top two of each subset: 64 or 128 values) of query q, one wave per query
+template <int J>
 __global__ __launch_bounds__(256) void knn_tau_kernel(const float* __restrict__ part_val, int N, int k, float* __restrict__ tau0) {
   const int lane = threadIdx.x & 63, q = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= N) return;
-  float v[1] = {part_val[(int64_t)q * kSplits * 8 + lane]};
-  const float t = wave_kth_largest<1>(v, k, lane);
+  float v[J];
+#pragma unroll
+  for (int i = 0; i < J; ++i) v[i] = part_val[(int64_t)q * (64 * J) + lane + 64 * i];
+  const float t = wave_kth_largest<J>(v, k, lane);
   if (lane == 0) tau0[q] = t;
 }
 
@@ -402,25 +421,58 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
 
 inline size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// 256 x 256 tiles once N / 256 query tiles x 8 splits fill the chip several times over;
+// DGMI_KNN_BIG_MIN_ROWS overrides the crossover (tools/knn_crossover.py)
+bool screen_big(int64_t N) {
+  static const int64_t min_rows = [] {
+    const char* e = getenv("DGMI_KNN_BIG_MIN_ROWS");
+    const long long v = e != nullptr ? atoll(e) : 0;
+    return (int64_t)(v > 0 ? v : kScreenBigMinRows);
+  }();
+  return N >= min_rows;
+}
+
 struct ScreenLayout {
+  bool big;
   int Np, Dp, cap;
   size_t xb, part, tau, cnt, buf, flags, total;
 };
 
 ScreenLayout screen_layout(int64_t N, int64_t D, int k) {
   ScreenLayout L;
-  L.Np = (int)((N + kSQ - 1) / kSQ * kSQ);
+  L.big = screen_big(N);
+  const int tile = L.big ? Shape<true>::kTile : Shape<false>::kTile;
+  L.Np = (int)((N + tile - 1) / tile * tile);
   L.Dp = (int)((D + kSK - 1) / kSK * kSK);
   L.cap = k <= 8 ? 64 : 128;
   size_t at = 0;
   L.xb = at, at += align256((size_t)L.Np * L.Dp * 2);
-  L.part = at, at += align256((size_t)N * kSplits * 8 * 4);
+  L.part = at, at += align256((size_t)N * Shape<true>::kSubsets * 2 * 4);
   L.tau = at, at += align256((size_t)N * 4);
   L.cnt = at, at += align256((size_t)N * kSplits * 4);
   L.buf = at, at += align256((size_t)N * kSplits * L.cap * 8);
   L.flags = at, at += align256((size_t)N * 4);
   L.total = at;
   return L;
+}
+
+template <bool BIG>
+hipError_t launch_screen(const ScreenArgs& a, int64_t N, int k, hipStream_t s) {
+  using S = Shape<BIG>;
+  const int n_groups = (a.Np / S::kTile + 7) / 8;
+  const unsigned blocks = (unsigned)(8 * ((n_groups + 7) / 8) * 64);
+  const size_t lds_sample = 2 * S::kStage, lds_emit = 2 * S::kStage + S::kTile * 4;
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<false, BIG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sample);
+  if (err != hipSuccess) return err;
+  err = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<true, BIG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_emit);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL((knn_screen_kernel<false, BIG>), dim3(blocks), dim3(S::kThreads), lds_sample, s, a);
+  hipLaunchKernelGGL((knn_tau_kernel<S::kSubsets * 2 / 64>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a.part_val, (int)N, k,
+                     const_cast<float*>(a.tau0));
+  hipLaunchKernelGGL((knn_screen_kernel<true, BIG>), dim3(blocks), dim3(S::kThreads), lds_emit, s, a);
+  return hipGetLastError();
 }
 
 }  // namespace
@@ -456,18 +508,8 @@ hipError_t knn_cosine_topk_screened(const float* Xn, int64_t ld, int64_t N, int6
   ScreenArgs a;
   a.Xb = Xb, a.N = (int)N, a.Np = L.Np, a.Dp = L.Dp, a.k = k, a.cap = L.cap;
   a.part_val = part, a.tau0 = tau0, a.cnt = cnt, a.buf = buf;
-  const int n_groups = (L.Np / kSQ + 7) / 8;
-  const unsigned blocks = (unsigned)(8 * ((n_groups + 7) / 8) * 64);
-  const size_t lds_lists = 2 * kStageBytes, lds_emit = 2 * kStageBytes + kSQ * 4;
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lists);
+  hipError_t err = L.big ? launch_screen<true>(a, N, k, s) : launch_screen<false>(a, N, k, s);
   if (err != hipSuccess) return err;
-  err = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds_emit);
-  if (err != hipSuccess) return err;
-  hipLaunchKernelGGL(knn_screen_kernel<false>, dim3(blocks), dim3(kSThreads), lds_lists, s, a);
-  hipLaunchKernelGGL(knn_tau_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, part, (int)N, k, tau0);
-  hipLaunchKernelGGL(knn_screen_kernel<true>, dim3(blocks), dim3(kSThreads), lds_emit, s, a);
   const dim3 rgrid((unsigned)((N + 3) / 4));
   if (L.cap == 64)
     hipLaunchKernelGGL(knn_rescore_kernel<8>, rgrid, dim3(256), 0, s, Xn, ld, (int)N, (int)D, k, L.cap, cnt, buf, nbr, flags);

@@ -14,6 +14,7 @@
 // nnz * 4F bytes of gather that now come out of L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "dgmi_kernels.h"
 #include "dgmi_segment.h"
@@ -265,7 +266,25 @@ hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s) {
   for (int64_t r0 = 0; r0 < a.n_dst; r0 += chunk) {
     const int64_t r1 = r0 + chunk < a.n_dst ? r0 + chunk : a.n_dst;
     hipError_t err;
-    switch (pick_lpr(a.F)) {  // widest lane group whose last column tile is still >= 85 % used
+    // Lane-group width = column tile.  Widest group whose last column tile is still >= 85 % used — unless
+    // the slice of X one XCD gathers from (n_src / n_slices rows x 16 LPR bytes) is just past its 4 MiB L2
+    // (4-8 MiB): then half the width.  The column tiles are grid.y, dispatched one after the other, so the
+    // XCD sweeps its slice twice at half the footprint.  Measured at F = 128 (bench.py): 100k-source table
+    // (6.4 -> 3.2 MB per pass) 0.379 -> 0.365 ms unweighted, 0.512 -> 0.464 ms kNN-64 weighted; a 50k-source
+    // table (already 3.2 MB) loses 10 % when halved, so the rule is tied to the footprint.
+    // DGMI_SLICED_LPR forces a width (tools).
+    static const int forced_lpr = [] {
+      const char* e = getenv("DGMI_SLICED_LPR");
+      return e != nullptr ? atoi(e) : 0;
+    }();
+    int lpr = pick_lpr(a.F);
+    if (lpr >= 32) {
+      const int64_t width = 16 * (int64_t)lpr < 4 * a.F ? 16 * (int64_t)lpr : 4 * a.F;
+      const int64_t slice_bytes = (a.n_src + a.n_slices - 1) / a.n_slices * width;
+      if (slice_bytes > (4 << 20) && slice_bytes <= (8 << 20)) lpr /= 2;
+    }
+    if (forced_lpr == 8 || forced_lpr == 16 || forced_lpr == 32 || forced_lpr == 64) lpr = forced_lpr;
+    switch (lpr) {
       case 8: err = launch_sliced<8>(a, r0, r1, s); break;
       case 16: err = launch_sliced<16>(a, r0, r1, s); break;
       case 32: err = launch_sliced<32>(a, r0, r1, s); break;

@@ -606,27 +606,22 @@ def similarity_graph(sim: torch.Tensor, k: int, symm: bool = True) -> torch.Tens
     return _normalized_adjacency(rows, nbr.reshape(-1), n, symm)
 
 
-# measured crossover of the fused kNN kernel against torch GEMM + top-k (tools/knn_bench.py)
-FUSED_KNN_MAX_ROWS = 16384
-
-
 def feature_similarity_graph(features: torch.Tensor, k: int, symm: bool = True,
                              block_rows: int = 8192, fused=None) -> torch.Tensor:
     """``_create_feature_similarity_graph`` (data_loader.py:312-344): cosine-similarity kNN graph
     from embeddings; the N x N similarity matrix is never materialised.  On the GPU the neighbour
-    search is one fused kernel (``ops.knn_cosine_topk``) when the shape fits it (D % 8 == 0, k <= 16 —
-    the reference runs k = 4 on 768-d embeddings, train.py:423) and N <= ``FUSED_KNN_MAX_ROWS`` (the
-    reference's datasets have N <= 763, where the kernel measures 1.1-1.5x the torch path; from
-    N ~ 20k the library GEMM's larger tiles win — DESIGN.md 4.7); otherwise, or with ``fused=False``,
-    a row-blocked torch GEMM + top-k (an 8192-row block against 100k columns is 3.3 GB of fp32,
-    reduced to k ids per row at once).  ``fused=True`` insists on the kernel at any N."""
+    search is ``ops.knn_cosine_topk`` when the shape fits it (D % 8 == 0, k <= 16 — the reference runs
+    k = 4 on 768-d embeddings, train.py:423): fp32-MFMA tiles + on-chip top-k at the reference's sizes,
+    a bf16-MFMA screen with exact fp32 rescoring from 1536 rows (1.5x / 8.6x the torch path at
+    N = 763 / 100 000); otherwise, or with ``fused=False``, a row-blocked torch GEMM +
+    top-k (an 8192-row block against 100k columns is 3.3 GB of fp32, reduced to k ids per row at
+    once).  ``fused=True`` insists on the kernel."""
     n = features.shape[0]
     k_actual = min(k, n - 1)
     norms = features.norm(dim=1, keepdim=True)
     norms = torch.where(norms == 0, torch.full_like(norms, 1e-10), norms)  # data_loader.py:334-335
     xn = features / norms
     if (fused is not False and xn.is_cuda and xn.dtype == torch.float32 and k_actual >= 1
-            and (fused is True or n <= FUSED_KNN_MAX_ROWS)
             and ops.knn_cosine_supported(n, xn.shape[1], k_actual)):
         # fused HIP kernel: fp32-MFMA similarity tiles + running top-k on chip (csrc/dgmi_knn.hip)
         nbr = ops.knn_cosine_topk(xn.contiguous(), k_actual).long()

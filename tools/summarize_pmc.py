@@ -55,13 +55,18 @@ with open(os.path.join(out, tag + "_pmc_summary.csv"), "w", newline="") as fh:
     wr.writeheader()
     wr.writerows(rows)
 
-main = [r for r in rows if r["kernel"].startswith("spmm_sliced_vec4_kernel<32, false, true, false>")]
+# dominant products (GCMC, unweighted, source-scaled): the 50k-source direction runs the 32-lane form, the
+# 100k-source direction the 16-lane form (two column passes: grid.y) — average them by launch count
+main = [r for r in rows if r["kernel"].startswith(("spmm_sliced_vec4_kernel<32, false, true, false>",
+                                                   "spmm_sliced_vec4_kernel<16, false, true, false>"))]
 red = [r for r in rows if r["kernel"].startswith("reduce_planes_kernel<true")]
 dom = None
 if main and red:
-    dom = [{"kernel": main[0]["kernel"] + " + " + red[0]["kernel"],
-            "hbm_bytes_corrected_avg": main[0]["hbm_bytes_corrected_avg"] + red[0]["hbm_bytes_corrected_avg"],
-            "L2_hit_rate": main[0]["L2_hit_rate"]}]
+    n = sum(r["launches"] for r in main)
+    gather = sum(r["hbm_bytes_corrected_avg"] * r["launches"] for r in main) / n
+    dom = [{"kernel": " | ".join(r["kernel"] for r in main) + " + " + red[0]["kernel"],
+            "hbm_bytes_corrected_avg": int(gather + red[0]["hbm_bytes_corrected_avg"]),
+            "L2_hit_rate": {r["kernel"]: r["L2_hit_rate"] for r in main}}]
 if dom:
     json.dump({"kernel": dom[0]["kernel"], "hbm_bytes_per_launch": dom[0]["hbm_bytes_corrected_avg"],
                "source": "profiles/%s_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
