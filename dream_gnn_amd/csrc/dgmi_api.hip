@@ -222,11 +222,11 @@ DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices,
                                   const int32_t* eid, const uint32_t* keep, int32_t n_keep,
                                   const float* X, int64_t ldx, const float* src_scale,
                                   const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
-                                  int64_t n_src, int64_t F, int32_t n_slices, void* planes,
+                                  int64_t n_src, int64_t F, int32_t n_slices, int32_t column_passes, void* planes,
                                   size_t planes_bytes, int32_t act, float act_slope, const float* out_mask,
                                   int64_t ld_mask, float out_mask_scale, dgmi_stream_t stream) {
   if (n_dst < 0 || n_src < 0 || F < 0 || n_slices < 1 || n_slices > 64 || !keep_args_ok(eid, keep, n_keep) ||
-      !epilogue_ok(act, out_mask, ld_mask, F))
+      !epilogue_ok(act, out_mask, ld_mask, F) || column_passes < 0 || column_passes > 1)
     return DGMI_ERR_INVALID_ARG;
   if (out_mask != nullptr && (ld_mask % 4 != 0 || (reinterpret_cast<uintptr_t>(out_mask) & 15))) return DGMI_ERR_INVALID_ARG;
   if (n_dst >= INT32_MAX || n_src >= INT32_MAX || F > INT32_MAX) return DGMI_ERR_TOO_LARGE;
@@ -241,7 +241,7 @@ DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices,
   if (planes_bytes < dgmi_spmm_sliced_planes_bytes(n_dst, n_slices, F)) return DGMI_ERR_WORKSPACE;
   dgmi::SlicedArgs a{segptr, indices, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F, n_slices,
                      static_cast<float*>(planes), F, sliced_chunk_rows(n_dst, n_slices, F), eid, keep, n_keep,
-                     {act, act_slope, out_mask, ld_mask, out_mask_scale}};
+                     {act, act_slope, out_mask, ld_mask, out_mask_scale}, column_passes == 1};
   return from_hip(dgmi::spmm_sliced_f32(a, as_stream(stream)));
 }
 

@@ -127,6 +127,7 @@ struct SlicedArgs {
   const void* keep;
   int n_keep;
   Epilogue ep;
+  bool full_width;         // never split the columns into half-width passes (see spmm_sliced_f32)
 };
 hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s);
 

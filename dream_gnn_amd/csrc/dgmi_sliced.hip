@@ -267,21 +267,26 @@ hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s) {
     const int64_t r1 = r0 + chunk < a.n_dst ? r0 + chunk : a.n_dst;
     hipError_t err;
     // Lane-group width = column tile.  Widest group whose last column tile is still >= 85 % used — unless
-    // the slice of X one XCD gathers from (n_src / n_slices rows x 16 LPR bytes) is just past its 4 MiB L2
-    // (4-8 MiB): then half the width.  The column tiles are grid.y, dispatched one after the other, so the
-    // XCD sweeps its slice twice at half the footprint.  Measured at F = 128 (bench.py): 100k-source table
-    // (6.4 -> 3.2 MB per pass) 0.379 -> 0.365 ms unweighted, 0.512 -> 0.464 ms kNN-64 weighted; a 50k-source
-    // table (already 3.2 MB) loses 10 % when halved, so the rule is tied to the footprint.
+    // the slice of X one XCD gathers from (n_src / n_slices rows x 16 LPR bytes) is larger than its 4 MiB
+    // L2: then half the width.  The column tiles are grid.y, dispatched one after the other, so the XCD
+    // sweeps its slice twice at half the footprint.  Measured at F = 128: 100k-source table (6.4 -> 3.2 MB
+    // per pass, bench.py) 0.379 -> 0.365 ms unweighted, 0.512 -> 0.464 ms kNN-64 weighted; config-5 shards
+    // (tools/cfg5_forms_probe.py) 204 MB table 0.740 -> 0.663 ms, 409 MB table 0.741 -> 0.712 ms (the halves
+    // of all 8 slices together fit the 256 MiB Infinity Cache; a quarter width gains nothing more).  A
+    // 50k-source table (already 3.2 MB per slice) loses 10-18 % when halved, so the rule is tied to the
+    // footprint; and a graph whose time is set by a few very long (virtual) rows pays their dependent gather
+    // chain once per pass (Zipf(1.2), 2048-edge virtual rows: 0.47 -> 0.62 ms), so its caller asks for full width.
+    // With edge dropout on the fly every pass re-evaluates keep(eid[p]) per edge (0.386 -> 0.408 ms): full width.
     // DGMI_SLICED_LPR forces a width (tools).
     static const int forced_lpr = [] {
       const char* e = getenv("DGMI_SLICED_LPR");
       return e != nullptr ? atoi(e) : 0;
     }();
     int lpr = pick_lpr(a.F);
-    if (lpr >= 32) {
+    if (lpr >= 32 && !a.full_width && a.n_keep == 0) {
       const int64_t width = 16 * (int64_t)lpr < 4 * a.F ? 16 * (int64_t)lpr : 4 * a.F;
       const int64_t slice_bytes = (a.n_src + a.n_slices - 1) / a.n_slices * width;
-      if (slice_bytes > (4 << 20) && slice_bytes <= (8 << 20)) lpr /= 2;
+      if (slice_bytes > (4 << 20)) lpr /= 2;
     }
     if (forced_lpr == 8 || forced_lpr == 16 || forced_lpr == 32 || forced_lpr == 64) lpr = forced_lpr;
     switch (lpr) {

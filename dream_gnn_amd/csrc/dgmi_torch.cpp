@@ -253,7 +253,7 @@ Tensor spmm_csr_raw(const Tensor& indptr, const Tensor& indices, const OptTensor
 Tensor spmm_sliced_raw(const Tensor& segptr, const Tensor& indices, const OptTensor& vals, const OptTensor& eid,
                        const OptTensor& keep, const Tensor& X, const OptTensor& src_scale, const OptTensor& dst_scale,
                        int64_t n_dst, int64_t n_slices, const OptTensor& out, int64_t act = 0, double slope = 0.0,
-                       const OptTensor& out_mask = c10::nullopt, double mask_scale = 1.0) {
+                       const OptTensor& out_mask = c10::nullopt, double mask_scale = 1.0, int64_t column_passes = 0) {
   check(segptr, at::kInt, 1, "segptr", segptr);
   check(indices, at::kInt, 1, "indices", segptr);
   TORCH_CHECK(segptr.numel() == n_slices * n_dst + 1, "segptr has ", segptr.numel(), " entries, expected n_slices * n_dst + 1");
@@ -272,8 +272,8 @@ Tensor spmm_sliced_raw(const Tensor& segptr, const Tensor& indices, const OptTen
   check_status(dgmi_spmm_sliced_f32(segptr.data_ptr<int32_t>(), indices.data_ptr<int32_t>(), (const float*)optptr(vals), k.eid,
                                     k.table, k.n, x.t.data_ptr<float>(), x.ld, (const float*)optptr(src_scale),
                                     (const float*)optptr(dst_scale), y.data_ptr<float>(), x.F, n_dst, x.rows, x.F,
-                                    (int32_t)n_slices, planes.data_ptr(), pbytes, e.act, e.slope, e.mask, e.ldm, e.mscale,
-                                    stream_of(segptr)), "dgmi_spmm_sliced_f32");
+                                    (int32_t)n_slices, (int32_t)column_passes, planes.data_ptr(), pbytes, e.act, e.slope, e.mask,
+                                    e.ldm, e.mscale, stream_of(segptr)), "dgmi_spmm_sliced_f32");
   return y;
 }
 
@@ -410,14 +410,17 @@ void spmm_csr_out(const Tensor& indptr, const Tensor& indices, const OptTensor& 
 }
 Tensor spmm_sliced_new(const Tensor& segptr, const Tensor& indices, const OptTensor& vals, const OptTensor& eid,
                        const OptTensor& keep, const Tensor& X, const OptTensor& ss, const OptTensor& ds, int64_t n_dst,
-                       int64_t n_slices, int64_t act, double slope, const OptTensor& out_mask, double mask_scale) {
+                       int64_t n_slices, int64_t act, double slope, const OptTensor& out_mask, double mask_scale,
+                       int64_t column_passes) {
   return spmm_sliced_raw(segptr, indices, vals, eid, keep, X, ss, ds, n_dst, n_slices, c10::nullopt, act, slope, out_mask,
-                         mask_scale);
+                         mask_scale, column_passes);
 }
 void spmm_sliced_out(const Tensor& segptr, const Tensor& indices, const OptTensor& vals, const OptTensor& eid,
                      const OptTensor& keep, const Tensor& X, const OptTensor& ss, const OptTensor& ds, int64_t n_dst,
-                     int64_t n_slices, Tensor out, int64_t act, double slope, const OptTensor& out_mask, double mask_scale) {
-  spmm_sliced_raw(segptr, indices, vals, eid, keep, X, ss, ds, n_dst, n_slices, out, act, slope, out_mask, mask_scale);
+                     int64_t n_slices, Tensor out, int64_t act, double slope, const OptTensor& out_mask, double mask_scale,
+                     int64_t column_passes) {
+  spmm_sliced_raw(segptr, indices, vals, eid, keep, X, ss, ds, n_dst, n_slices, out, act, slope, out_mask, mask_scale,
+                  column_passes);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -481,10 +484,11 @@ TORCH_LIBRARY(dreamgnn_mi, m) {
         "Tensor? dst_scale, Tensor? plan, int chunk, Tensor(a!) out, int act=0, float slope=0., Tensor? out_mask=None, "
         "float mask_scale=1.) -> ()");
   m.def("spmm_sliced_raw(Tensor segptr, Tensor indices, Tensor? vals, Tensor? eid, Tensor? keep, Tensor X, Tensor? src_scale, "
-        "Tensor? dst_scale, int n_dst, int n_slices, int act=0, float slope=0., Tensor? out_mask=None, float mask_scale=1.) -> Tensor");
+        "Tensor? dst_scale, int n_dst, int n_slices, int act=0, float slope=0., Tensor? out_mask=None, float mask_scale=1., "
+        "int column_passes=0) -> Tensor");
   m.def("spmm_sliced_out(Tensor segptr, Tensor indices, Tensor? vals, Tensor? eid, Tensor? keep, Tensor X, Tensor? src_scale, "
         "Tensor? dst_scale, int n_dst, int n_slices, Tensor(a!) out, int act=0, float slope=0., Tensor? out_mask=None, "
-        "float mask_scale=1.) -> ()");
+        "float mask_scale=1., int column_passes=0) -> ()");
   m.def("epilogue_backward(Tensor dY, Tensor Y, Tensor? mask, int act, float slope, float mask_scale) -> Tensor");
   m.def("knn_cosine_topk(Tensor Xn, int k) -> Tensor");
   m.def("gather_f32(Tensor values, Tensor perm) -> Tensor");

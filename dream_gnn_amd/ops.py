@@ -198,10 +198,11 @@ class SlicedCSR:
 
     _DEFAULT = object()
 
-    def spmm(self, X, src_scale=None, dst_scale=None, out=None, vals=_DEFAULT, keep=None, epi=None):
+    def spmm(self, X, src_scale=None, dst_scale=None, out=None, vals=_DEFAULT, keep=None, epi=None, full_width=False):
         """``vals`` (in sliced order, see ``eid``) overrides the values given at construction;
         ``keep``: subset descriptions applied through ``eid`` (edge dropout on the fly); ``epi``: output
-        epilogue (act, slope, out_mask, mask_scale) applied by the plane-reduce kernel."""
+        epilogue (act, slope, out_mask, mask_scale) applied by the plane-reduce kernel; ``full_width``:
+        never sweep the columns in two half-width passes (``column_passes = 1`` of the C ABI)."""
         vals = self.vals if vals is SlicedCSR._DEFAULT else vals
         if not X.is_cuda or X.device != self.segptr.device:
             _require_device(self.segptr, X)
@@ -211,9 +212,10 @@ class SlicedCSR:
                 None if keep is None else _prep_keep(keep), X, None if src_scale is None else src_scale.reshape(-1),
                 None if dst_scale is None else dst_scale.reshape(-1), self.n_dst, self.n_slices)
         epi = epi or _NO_EPI
+        passes = 1 if full_width else 0
         if out is None:
-            return _T.spmm_sliced_raw(*args, *epi)
-        _T.spmm_sliced_out(*args, out, *epi)
+            return _T.spmm_sliced_raw(*args, *epi, passes)
+        _T.spmm_sliced_out(*args, out, *epi, passes)
         return out
 
 
@@ -282,7 +284,8 @@ class _SplitSliced:
         self.n_rows = n_rows
 
     def spmm(self, X, src_scale, dst_scale, out, vals, keep=None, epi=None):
-        yv = self.sliced.spmm(X, src_scale, None, None, vals=vals, keep=keep)
+        # full width: the long virtual rows' gather chains set the time, and each column pass repeats them
+        yv = self.sliced.spmm(X, src_scale, None, None, vals=vals, keep=keep, full_width=True)
         F = yv.shape[1]
         if out is None:
             out = torch.empty((self.n_rows, F), dtype=torch.float32, device=yv.device)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 13
+#define DGMI_ABI_VERSION 14
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -193,7 +193,12 @@ DGMI_API int dgmi_gather_f32(const float* in, const int32_t* perm, int64_t n, fl
  *                                  (n_cols is required here; n_slices in [1, 64])
  *   planes = device scratch of dgmi_spmm_sliced_planes_bytes(n_dst, n_slices, F) bytes
  *   dgmi_spmm_sliced_f32           requires F % 4 == 0, ldx % 4 == 0, ldy % 4 == 0 and 16-B
- *                                  aligned X / Y / planes (returns DGMI_ERR_INVALID_ARG otherwise)
+ *                                  aligned X / Y / planes (returns DGMI_ERR_INVALID_ARG otherwise).
+ *                                  column_passes: 0 = automatic — when an XCD's slice of X
+ *                                  (n_src / n_slices rows) exceeds its 4 MiB L2 the columns are swept
+ *                                  in two half-width passes (half the footprint each; +4-10 % on
+ *                                  regular graphs); 1 = always one full-width pass (graphs whose time
+ *                                  is set by a few very long rows: every pass repeats their chain)
  */
 DGMI_API int dgmi_csr_sliced_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
                                           int64_t n_rows, int64_t n_cols, int32_t n_slices,
@@ -205,8 +210,8 @@ DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices,
                                   const int32_t* eid, const uint32_t* keep, int32_t n_keep,
                                   const float* X, int64_t ldx, const float* src_scale,
                                   const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
-                                  int64_t n_src, int64_t F, int32_t n_slices, void* planes,
-                                  size_t planes_bytes, int32_t act, float act_slope,
+                                  int64_t n_src, int64_t F, int32_t n_slices, int32_t column_passes,
+                                  void* planes, size_t planes_bytes, int32_t act, float act_slope,
                                   const float* out_mask, int64_t ld_mask, float out_mask_scale,
                                   dgmi_stream_t stream);
 
