@@ -275,7 +275,8 @@ hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s) {
     // of all 8 slices together fit the 256 MiB Infinity Cache; a quarter width gains nothing more).  A
     // 50k-source table (already 3.2 MB per slice) loses 10-18 % when halved, so the rule is tied to the
     // footprint; and a graph whose time is set by a few very long (virtual) rows pays their dependent gather
-    // chain once per pass (Zipf(1.2), 2048-edge virtual rows: 0.47 -> 0.62 ms), so its caller asks for full width.
+    // chain once per pass (Zipf(1.2) cut into 2048-edge virtual rows: 0.47 -> 0.62 ms; at the 512 edges
+    // ops._SplitSliced uses the passes win again, 0.435 -> 0.418 ms): such a caller can ask for full width.
     // With edge dropout on the fly every pass re-evaluates keep(eid[p]) per edge (0.386 -> 0.408 ms): full width.
     // DGMI_SLICED_LPR forces a width (tools).
     static const int forced_lpr = [] {

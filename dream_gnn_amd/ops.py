@@ -254,8 +254,11 @@ class _Structure:
 
 
 # Rows longer than this are cut into virtual rows before the XCD-local kernel sees them (power-law
-# graphs): a (virtual row, slice) segment is then at most SPLIT_ROW_EDGES / 8 edges long.
-SPLIT_ROW_EDGES = 2048
+# graphs): a (virtual row, slice) segment is then at most SPLIT_ROW_EDGES / 8 edges long.  A lane group
+# streams 8 consecutive virtual rows of a slice as one dependent chain, so this length sets the critical
+# path of the launch: Zipf(1.2), 10 M edges (tools/zipf_split_probe.py) 0.477 ms at 2048, 0.443 at 1024,
+# 0.418 at 512 (with the launcher's column passes), 0.439 at 256.
+SPLIT_ROW_EDGES = 512
 
 
 class _SplitSliced:
@@ -284,8 +287,7 @@ class _SplitSliced:
         self.n_rows = n_rows
 
     def spmm(self, X, src_scale, dst_scale, out, vals, keep=None, epi=None):
-        # full width: the long virtual rows' gather chains set the time, and each column pass repeats them
-        yv = self.sliced.spmm(X, src_scale, None, None, vals=vals, keep=keep, full_width=True)
+        yv = self.sliced.spmm(X, src_scale, None, None, vals=vals, keep=keep)
         F = yv.shape[1]
         if out is None:
             out = torch.empty((self.n_rows, F), dtype=torch.float32, device=yv.device)

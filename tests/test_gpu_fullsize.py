@@ -136,11 +136,11 @@ def test_power_law_degrees_full_size(oracle, dev):
     X = torch.randn(ND, F, generator=gen, device=dev)
     y = g.spmm(X)
     assert torch.equal(y, g.spmm(X))
-    # not regular -> rows cut into virtual rows of <= 2048 edges, XCD-local kernel on those, ordered re-sum
+    # not regular -> rows cut into virtual rows of <= SPLIT_ROW_EDGES edges, XCD-local kernel on those, ordered re-sum
     assert not g.regular
     if not FORCED:
         assert g._S.split is not None and g._S.sliced is None
-        assert g._S.split.n_virtual == int(torch.clamp((deg + 2047) // 2048, min=1).sum())
+        assert g._S.split.n_virtual == int(torch.clamp((deg + ops.SPLIT_ROW_EDGES - 1) // ops.SPLIT_ROW_EDGES, min=1).sum())
     y_planned = ops.spmm_csr_raw(g.indptr, g.indices, None, X, plan=g.plan)
     assert float((y - y_planned).abs().max()) <= 1e-5 * float(y_planned.abs().max())
     ones = g.spmm(torch.ones(ND, F, device=dev))
