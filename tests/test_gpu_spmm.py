@@ -282,6 +282,36 @@ def test_xcd_sliced_spmm_vs_oracle(oracle, dev, F, mode, n_slices):
     assert np.array_equal(y, sl.spmm(t(X), t(ss), t(ds)).cpu().numpy())  # reproducible
 
 
+@pytest.mark.parametrize("F", [128, 256, 344, 64])
+@pytest.mark.parametrize("mode", ["copy_u", "all"])
+def test_xcd_sliced_column_passes(oracle, dev, F, mode):
+    """With > 65536 sources at F = 128 an XCD's slice of X exceeds its 4 MiB L2 and the launcher sweeps the
+    columns in two half-width passes (16-lane groups; F = 256: 64 -> 32 lanes; F = 344: a ragged last tile;
+    F = 64: slice still under 4 MiB, one pass).  The per-element sum order does not depend on the column
+    tiling: bit-identical to the single full-width pass (`column_passes = 1`), and within 1e-5 of f64."""
+    from dream_gnn_amd import ops
+
+    rng = np.random.default_rng(F)
+    n_dst, n_src, E = 301, 70001, 60000
+    dst, src = _rand_graph(rng, n_dst, n_src, E)
+    X = rng.standard_normal((n_src, F)).astype(np.float32)
+    vals = rng.standard_normal(E).astype(np.float32) if mode == "all" else None
+    ss = rng.uniform(0.1, 1.0, n_src).astype(np.float32) if mode == "all" else None
+    ds = rng.uniform(0.1, 1.0, n_dst).astype(np.float32) if mode == "all" else None
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    sl = ops.SlicedCSR(t(dst), t(src), n_dst, n_src, vals=t(vals))
+    y_auto = sl.spmm(t(X), t(ss), t(ds))
+    y_full = sl.spmm(t(X), t(ss), t(ds), full_width=True)
+    assert torch.equal(y_auto, y_full)
+    ip, ix, e0 = oracle.csr_from_coo(dst, src, n_dst)
+    v0 = None if vals is None else vals[e0]
+    y64 = oracle.spmm_csr(ip, ix, v0, X, ss, ds, acc="f64")
+    yabs = oracle.spmm_csr(ip, ix, v0, X, ss, ds, acc="abs")
+    y = y_auto.cpu().numpy()
+    assert np.all(np.abs(y - y64) <= RTOL * yabs + 1e-30)
+    assert np.abs(y - y64).max() <= RTOL * np.abs(y64).max()
+
+
 def test_xcd_sliced_edge_cases(oracle, dev):
     from dream_gnn_amd import ops
 
