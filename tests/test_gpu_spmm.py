@@ -426,9 +426,12 @@ def test_gather_add_forward_backward(oracle, dev, F):
 
 
 @pytest.mark.parametrize("E,keep", [(1, 1), (7, 3), (1000, 1), (1000, 999), (1000, 1000), (1000, 0), (123457, 111111),
-                                    (3_000_000, 2_700_000)])
+                                    (1048575, 524288), (1048576, 943718), (1048577, 1), (1048577, 1048576),
+                                    (3_000_000, 2_700_000), (3_000_000, 3_000_000), (3_000_000, 0), (10_000_000, 9_000_000)])
 def test_random_subset_mask_bit_exact(oracle, dev, E, keep):
-    """(D3) exact-size random edge selection: integer work, bit-exact against the oracle."""
+    """(D3) exact-size random edge selection: integer work, bit-exact against the oracle.  Lists below
+    2^20 edges are selected by one workgroup (radix select), longer ones by the uniform-window passes
+    (keep = 1 / E - 1 at the window's edge of the hash space; keep = E and 0: the direct paths)."""
     from dream_gnn_amd import ops
 
     for seed in (0, 12345678901234567):
@@ -467,7 +470,8 @@ def test_edge_dropout_select_path_no_sync_and_same_product(dev):
 
 
 @pytest.mark.parametrize("E,keep,off", [(1, 1, 0), (7, 3, 5), (1000, 1, 0), (1000, 999, 17), (1000, 1000, 0), (1000, 0, 3),
-                                        (123457, 111111, 1_000_000), (2_000_003, 1_800_002, 0)])
+                                        (123457, 111111, 1_000_000), (2_000_003, 1_800_002, 0), (5_000_000, 2_500_000, 77),
+                                        (5_000_000, 4_999_999, 0), (5_000_000, 1, 0)])
 def test_random_subset_description_bit_exact(oracle, dev, E, keep, off):
     """(D3) the 8-word subset description and the mask derived from it: integer work, bit-exact."""
     from dream_gnn_amd import ops
@@ -545,13 +549,25 @@ def test_edge_dropout_on_the_fly_every_kernel(oracle, dev, F, weighted):
     assert np.all(np.abs(x.grad.cpu().numpy() - ref_t) <= RTOL * bound_t + 1e-30)
 
 
+def test_subset_selection_window_miss_is_taken_over_exactly(oracle, dev, monkeypatch):
+    """Long lists find the threshold inside an 8-sigma window of the hash space; if the window ever misses,
+    one workgroup selects the list on its own.  With the window narrowed to ~2 edges it (almost) always
+    misses: the description is still the oracle's, bit for bit."""
+    from dream_gnn_amd import ops
+
+    monkeypatch.setenv("DGMI_SELECT_NARROW_WINDOW", "1")
+    for E, keep, seed in ((1_500_000, 1_350_000, 3), (2_000_000, 1_000_000, 2 ** 63 + 5), (1_200_000, 7, 11)):
+        d = ops.random_subset_select(E, keep, seed, dev)
+        assert np.array_equal(d.cpu().numpy(), oracle.random_subset_select(E, keep, seed, 0))
+
+
 def test_batched_subset_selection_equals_single_calls(oracle, dev):
     """8 subsets from one series of launches (dgmi_random_subset_select_batch) == 8 single selections
     == the oracle, with different sizes, offsets and an empty keep among them."""
     from dream_gnn_amd import ops
 
-    Es = [1, 7, 1000, 465_000, 2_746, 100_003, 50, 6_800, 33, 12]  # 10 lists: two batches
-    keeps = [1, 3, 900, 418_500, 2_471, 0, 50, 6_120, 1, 11]
+    Es = [1, 7, 1000, 465_000, 2_746, 4_100_003, 50, 2_000_000, 33, 12]  # 10 lists: two batches, short and long lists mixed
+    keeps = [1, 3, 900, 418_500, 2_471, 0, 50, 1_800_000, 1, 11]
     seeds = [0, 1, 2 ** 64 - 1, 12345678901234567, 5, 6, 7, 2 ** 63, 9, 10]
     offs = [0, 5, 0, 1000, 0, 7, 0, 0, 3, 0]
     d = ops.random_subset_select_batch(Es, keeps, seeds, dev, offs)
