@@ -254,8 +254,9 @@ DGMI_API int dgmi_epilogue_backward_f32(const float* dY, const float* Y, const f
 /* -------------------------------------------------------------------------
  * (D3) Edge dropout selection: a uniformly random subset of exactly `keep` of E edges — what
  * `perm = randperm(E); keep = perm[:num_keep]` (augmentation.py:48-52, 114-118) selects,
- * without materialising the permutation: per-edge keys (hash32(seed, e), e), a 4-pass radix
- * select of the keep-th smallest, one pass that orders equal hashes by edge id.
+ * without materialising the permutation: per-edge keys (hash32(seed, e), e) and a SELECTION of the
+ * keep-th smallest key (lists below 2^20 edges: a radix select by one workgroup; longer lists: two
+ * passes over a window of the hash space around keep / E * 2^32, exact in every case).
  * Deterministic in (seed, E, keep).  workspace: dgmi_random_subset_workspace_bytes() bytes.
  * 0 <= keep <= E.
  *
