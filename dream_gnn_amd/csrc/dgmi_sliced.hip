@@ -22,6 +22,7 @@
 namespace dgmi {
 namespace {
 
+constexpr int64_t kColumnPassMinRows = 32768;  // column passes only when a pass still has >= ~8k waves
 constexpr int kRowsPerGroup = 8;  // <= LPR (row boundaries live one per lane of the group)
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -278,13 +279,16 @@ hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s) {
     // chain once per pass (Zipf(1.2) cut into 2048-edge virtual rows: 0.47 -> 0.62 ms; at the 512 edges
     // ops._SplitSliced uses the passes win again, 0.435 -> 0.418 ms): such a caller can ask for full width.
     // With edge dropout on the fly every pass re-evaluates keep(eid[p]) per edge (0.386 -> 0.408 ms): full width.
+    // Half-width groups also mean half as many waves per pass (n_dst / 4 at F = 128): with few, long rows the
+    // launch no longer fills the chip (config-5 edge-scaled shard, 6250 rows of 1600 edges: 0.382 -> 0.440 ms),
+    // so the rule needs kColumnPassMinRows destination rows.
     // DGMI_SLICED_LPR forces a width (tools).
     static const int forced_lpr = [] {
       const char* e = getenv("DGMI_SLICED_LPR");
       return e != nullptr ? atoi(e) : 0;
     }();
     int lpr = pick_lpr(a.F);
-    if (lpr >= 32 && !a.full_width && a.n_keep == 0) {
+    if (lpr >= 32 && !a.full_width && a.n_keep == 0 && a.n_dst >= kColumnPassMinRows) {
       const int64_t width = 16 * (int64_t)lpr < 4 * a.F ? 16 * (int64_t)lpr : 4 * a.F;
       const int64_t slice_bytes = (a.n_src + a.n_slices - 1) / a.n_slices * width;
       if (slice_bytes > (4 << 20)) lpr /= 2;

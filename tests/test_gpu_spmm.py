@@ -285,15 +285,16 @@ def test_xcd_sliced_spmm_vs_oracle(oracle, dev, F, mode, n_slices):
 @pytest.mark.parametrize("F", [128, 256, 344, 64])
 @pytest.mark.parametrize("mode", ["copy_u", "all"])
 def test_xcd_sliced_column_passes(oracle, dev, F, mode):
-    """With > 65536 sources at F = 128 an XCD's slice of X exceeds its 4 MiB L2 and the launcher sweeps the
-    columns in two half-width passes (16-lane groups; F = 256: 64 -> 32 lanes; F = 344: a ragged last tile;
+    """With > 65536 sources at F = 128 (and >= 32768 destination rows) an XCD's slice of X exceeds its 4 MiB L2
+    and the launcher sweeps the columns in two half-width passes (16-lane groups; F = 256: 64 -> 32 lanes; F = 344: a ragged last tile;
     F = 64: slice still under 4 MiB, one pass).  The per-element sum order does not depend on the column
     tiling: bit-identical to the single full-width pass (`column_passes = 1`), and within 1e-5 of f64."""
     from dream_gnn_amd import ops
 
     rng = np.random.default_rng(F)
-    n_dst, n_src, E = 301, 70001, 60000
+    n_dst, n_src, E = 33001, 70001, 90000
     dst, src = _rand_graph(rng, n_dst, n_src, E)
+    dst[:20000] = rng.integers(0, 300, 20000)  # some rows of ~70 edges among mostly short ones
     X = rng.standard_normal((n_src, F)).astype(np.float32)
     vals = rng.standard_normal(E).astype(np.float32) if mode == "all" else None
     ss = rng.uniform(0.1, 1.0, n_src).astype(np.float32) if mode == "all" else None
