@@ -630,7 +630,7 @@ def test_output_epilogue_in_every_kernel_form(dev, F, act, slope):
 
 
 @pytest.mark.parametrize("N,D,k", [(763, 768, 4), (681, 768, 4), (33, 8, 1), (1000, 64, 16), (5000, 768, 8), (32, 1024, 3),
-                                   (97, 24, 13), (1536, 64, 16), (16500, 16, 5), (20000, 768, 4), (9001, 200, 16), (50001, 72, 6)])
+                                   (97, 24, 13), (1536, 64, 16), (2048, 64, 1), (3001, 40, 2), (16500, 16, 5), (20000, 768, 4), (9001, 200, 16), (50001, 72, 6)])
 def test_fused_knn_kernel_finds_the_k_most_similar_rows(dev, N, D, k):
     """(f4) `dgmi_knn_cosine_topk_f32` (fp32 MFMA tiles + running top-k on chip) against a brute-force
     float64 similarity matrix: every row's selected neighbours are k distinct valid ids whose
