@@ -349,8 +349,8 @@ def variants(torch, dev, ops):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)   # >= 50 launches per product after >= 10 warm-ups
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra products and probes (profiling runs)")
     ap.add_argument("--scale", choices=["nodes", "edges"], default="nodes",

@@ -8,7 +8,7 @@ TAG=${1:-r02}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && export DGMI_SKIP_BUILD=1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-variants > $OUT/bench_under_trace.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-variants > $OUT/bench_under_trace.json 2> $OUT/trace.err
 echo "trace done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants > /dev/null 2> $OUT/pmc_fetch.err
 echo "fetch done"
