@@ -16,8 +16,11 @@
 //                                candidates it sees for its query (registers; 32 disjoint subsets per query)
 //      knn_tau_kernel            tau'(q) = k-th largest of those 64 scores of 64 distinct candidates: k
 //                                candidates reach it, so it is a lower bound of tau (k <= 16 < 64)
-//   3. knn_screen_kernel<EMIT>   all candidates: (id, approx) of every pair with approx >= tau' - 2 eps
-//                                appended to the query's buffer (LDS counters; order irrelevant)
+//   3. knn_screen_kernel<EMIT>   every pair with approx >= tau' - 2 eps is appended to the query's buffer
+//                                (one global counter per query; order irrelevant).  The similarity matrix is
+//                                symmetric, so only tile pairs (i, j >= i) are multiplied: a score is offered
+//                                to its column's query (the lane's) and, off the diagonal, to its row's query
+//                                too (thresholds of the candidate tile's rows in LDS) — half the MFMA work
 //   4. knn_rescore_kernel        one wave per query: tau from the buffer, exact fp32 dot products of the
 //                                entries >= tau - 2 eps, top-k by (score desc, id asc); a query whose
 //                                buffer overflowed is flagged
@@ -88,11 +91,16 @@ __global__ __launch_bounds__(256) void knn_to_bf16_kernel(const float* __restric
 
 struct ScreenArgs {
   const uint16_t* Xb;  // [Np][Dp] bf16
-  int N, Np, Dp, k, cap;  // Np: N rounded up to the tile
+  int N, Np, Dp, k;       // Np: N rounded up to the tile
+  int cap_r, cap_c;       // slots of one row-direction region / of the column-direction region of a query's buffer
   float* part_val;     // SAMPLE: [N][subsets][2] the two largest approx scores of each subset (kUnset: none)
   const float* tau0;   // EMIT: [N] lower bound of the k-th largest approx score
-  int32_t* cnt;        // EMIT: [N][kSplits] entries offered (may exceed cap: overflow)
-  int2* buf;           // EMIT: [N][kSplits][cap] (candidate id, approx bits)
+  // EMIT: a query's buffer = kSplits regions of cap_r slots, one per candidate split (filled by the one workgroup
+  // that owns (query tile, split): LDS counters, count written at the end) + one region of cap_c slots for the
+  // scores other workgroups offer it in the triangular sweep (a global counter, zeroed before the launch)
+  int32_t* cnt;        // [N][kSplits + 1] entries offered (may exceed the region: overflow)
+  int2* buf;           // [N][kSplits * cap_r + cap_c] (candidate id, approx bits)
+  int sym;             // EMIT: 1 = triangular sweep (tile pairs j >= i, scores offered in both directions)
 };
 
 template <bool EMIT, bool BIG>
@@ -101,7 +109,8 @@ __global__ __launch_bounds__(Shape<BIG>::kThreads, 2) void knn_screen_kernel(Scr
   constexpr int QS = S::kQS, kT = S::kTile, kStageBytes = S::kStage;
   extern __shared__ __align__(16) unsigned char screen_lds[];
   unsigned char* stage = screen_lds;                                             // [2][2 kT rows][128 B]
-  uint32_t* cnt_sh = reinterpret_cast<uint32_t*>(screen_lds + 2 * kStageBytes);  // EMIT: [kT]
+  uint32_t* cnt_sh = reinterpret_cast<uint32_t*>(screen_lds + 2 * kStageBytes);  // EMIT: [kT] entries of this (query, split) region
+  float* ethr_c = reinterpret_cast<float*>(cnt_sh + kT);  // EMIT, triangular: [kT] emission thresholds of the candidate tile's rows
 
   // block -> (query tile, candidate split): XCD x gets blocks x, x + 8, ...; 64 consecutive ones of an
   // XCD form one super-tile (8 query tiles of query group G, 8 splits)
@@ -115,8 +124,9 @@ __global__ __launch_bounds__(Shape<BIG>::kThreads, 2) void knn_screen_kernel(Scr
   // a split without a tile), dealt round-robin to the splits; EMIT = the split's contiguous range
   int t0, tstep, nt;
   if (EMIT) {
-    const int per = (n_tiles + kSplits - 1) / kSplits;
-    t0 = split * per;
+    const int first = a.sym ? q_tile : 0;  // triangular sweep: candidate tiles from the diagonal on
+    const int per = (n_tiles - first + kSplits - 1) / kSplits;
+    t0 = first + split * per;
     tstep = 1;
     nt = t0 + per <= n_tiles ? per : (n_tiles > t0 ? n_tiles - t0 : 0);
   } else {
@@ -211,6 +221,15 @@ __global__ __launch_bounds__(Shape<BIG>::kThreads, 2) void knn_screen_kernel(Scr
     const bool more = it + 1 < total;
     if (more) DGMI_SCREEN_GLOAD(ntile, nkc);
 
+    if (EMIT && kc == 0 && a.sym) {
+      // thresholds of this candidate tile's rows, for the scores offered to them; the previous tile's epilogue
+      // read the old ones before the barrier that ended its last chunk
+      if (tid < kT) {
+        const int cg = tile * kT + tid;
+        ethr_c[tid] = cg < a.N ? a.tau0[cg] - 2.f * kScreenEps : 4.0f;
+      }
+      if (nK == 1) __syncthreads();  // otherwise a barrier separates this write from the epilogue's reads
+    }
     const unsigned char* base = stage + (it & 1) * kStageBytes;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -247,9 +266,11 @@ __global__ __launch_bounds__(Shape<BIG>::kThreads, 2) void knn_screen_kernel(Scr
 #pragma unroll
           for (int v = 0; v < 16; ++v) mx = fmaxf(mx, acc[qs][cs][v]);
         if (EMIT) {
-          if (mx >= ethr[qs]) {
+          const int qg = q_wave + qs * 32 + r;  // this lane's query
+          const int64_t q_slots = (int64_t)kSplits * a.cap_r + a.cap_c;
+          if (mx >= ethr[qs]) {  // (ethr = 4 for a padding query: never)
             const int ql = wq * (32 * QS) + qs * 32 + r;
-            const int64_t row = ((int64_t)(q_tile * kT + ql) * kSplits + split) * a.cap;
+            const int64_t row = (int64_t)qg * q_slots + (int64_t)split * a.cap_r;
 #pragma unroll
             for (int cs = 0; cs < 2; ++cs)
 #pragma unroll
@@ -257,10 +278,41 @@ __global__ __launch_bounds__(Shape<BIG>::kThreads, 2) void knn_screen_kernel(Scr
                 const float s = acc[qs][cs][v];
                 if (s >= ethr[qs]) {
                   const uint32_t slot = atomicAdd(&cnt_sh[ql], 1u);
-                  if (slot < (uint32_t)a.cap)
+                  if (slot < (uint32_t)a.cap_r)
                     a.buf[row + slot] = make_int2(c_base + 32 * cs + 8 * (v >> 2) + 4 * h + (v & 3), __float_as_int(s));
                 }
               }
+          }
+          if (a.sym && tile != q_tile && qg < a.N) {
+            // the same scores, offered to the queries that are this tile's candidate rows (padding rows carry
+            // kMasked scores and a threshold of 4: never)
+            const float* tc = ethr_c + wc * 64 + 4 * h;
+            bool any = false;
+            float4 th[2][4];
+#pragma unroll
+            for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+              for (int g4 = 0; g4 < 4; ++g4) {  // rows 32 cs + 8 g4 + 4 h + (0..3)
+                th[cs][g4] = *reinterpret_cast<const float4*>(tc + 32 * cs + 8 * g4);
+                any |= acc[qs][cs][4 * g4] >= th[cs][g4].x || acc[qs][cs][4 * g4 + 1] >= th[cs][g4].y ||
+                       acc[qs][cs][4 * g4 + 2] >= th[cs][g4].z || acc[qs][cs][4 * g4 + 3] >= th[cs][g4].w;
+              }
+            if (any) {
+#pragma unroll
+              for (int cs = 0; cs < 2; ++cs)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                  const float s = acc[qs][cs][v];
+                  const float4 t4 = th[cs][v >> 2];
+                  const float t = (v & 3) == 0 ? t4.x : (v & 3) == 1 ? t4.y : (v & 3) == 2 ? t4.z : t4.w;
+                  if (s >= t) {
+                    const int cq = c_base + 32 * cs + 8 * (v >> 2) + 4 * h + (v & 3);  // the row's query
+                    const uint32_t slot = (uint32_t)atomicAdd(&a.cnt[(int64_t)cq * (kSplits + 1) + kSplits], 1);
+                    if (slot < (uint32_t)a.cap_c)
+                      a.buf[(int64_t)cq * q_slots + (int64_t)kSplits * a.cap_r + slot] = make_int2(qg, __float_as_int(s));
+                  }
+                }
+            }
           }
         } else if (mx > max2[qs]) {
 #pragma unroll
@@ -288,7 +340,8 @@ __global__ __launch_bounds__(Shape<BIG>::kThreads, 2) void knn_screen_kernel(Scr
   }
 
   if (EMIT) {
-    if (tid < kT && q_tile * kT + tid < a.N) a.cnt[(int64_t)(q_tile * kT + tid) * kSplits + split] = (int32_t)cnt_sh[tid];
+    if (tid < kT && q_tile * kT + tid < a.N)
+      a.cnt[(int64_t)(q_tile * kT + tid) * (kSplits + 1) + split] = (int32_t)cnt_sh[tid];
   } else {
 #pragma unroll
     for (int qs = 0; qs < QS; ++qs) {
@@ -344,24 +397,29 @@ __global__ __launch_bounds__(256) void knn_tau_kernel(const float* __restrict__ 
   if (lane == 0) tau0[q] = t;
 }
 
-// One wave per query: exact top-k among the screened candidates.  kJ = entries per lane (8 cap / 64).
+// One wave per query: exact top-k among the screened candidates.  kJ = buffer slots per lane
+// ((kSplits * cap_r + cap_c) / 64).
 template <int kJ>
-__global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restrict__ Xn, int64_t ld, int N, int D, int k, int cap,
-                                                          const int32_t* __restrict__ cnt, const int2* __restrict__ buf,
-                                                          int32_t* __restrict__ nbr, int32_t* __restrict__ flags) {
+__global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restrict__ Xn, int64_t ld, int N, int D, int k, int cap_r,
+                                                          int cap_c, const int32_t* __restrict__ cnt,
+                                                          const int2* __restrict__ buf, int32_t* __restrict__ nbr,
+                                                          int32_t* __restrict__ flags) {
   const int lane = threadIdx.x & 63, q = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= N) return;
-  // entries: slot e = lane + 64 i of the query's [kSplits][cap] buffer
+  // entries: slot e = lane + 64 i of the query's buffer; region e / cap_r (the last one cap_c wide)
   int32_t e_id[kJ];
   float e_s[kJ], work[kJ];
   bool over = false;
+  const int row_slots = kSplits * cap_r;
 #pragma unroll
   for (int i = 0; i < kJ; ++i) {
-    const int e = lane + 64 * i, sp = e / cap, at = e - sp * cap;
-    const int c = cnt[(int64_t)q * kSplits + sp];
-    over |= c > cap;
+    const int e = lane + 64 * i;
+    const int region = e < row_slots ? e / cap_r : kSplits;
+    const int at = e - region * cap_r;
+    const int c = cnt[(int64_t)q * (kSplits + 1) + region];
+    over |= c > (region < kSplits ? cap_r : cap_c);
     const bool live = at < c;
-    const int2 rec = live ? buf[((int64_t)q * kSplits + sp) * cap + at] : make_int2(-1, 0);
+    const int2 rec = live ? buf[(int64_t)q * (row_slots + cap_c) + e] : make_int2(-1, 0);
     e_id[i] = rec.x;
     e_s[i] = live ? __int_as_float(rec.y) : kMasked;
     work[i] = e_s[i];
@@ -432,9 +490,21 @@ bool screen_big(int64_t N) {
   return N >= min_rows;
 }
 
+// Triangular sweep (half the MFMA work, scores offered in both directions) once the workgroups of the first
+// query tiles no longer set the run time: measured crossover (tools/knn_sym_ab.py) N ~ 20 000 at k = 4,
+// ~ 40 000 at k = 16 (its second direction appends through global counters).  DGMI_KNN_SYM=0/1 overrides.
+bool screen_sym(int64_t N, int k) {
+  static const int forced = [] {
+    const char* e = getenv("DGMI_KNN_SYM");
+    return e == nullptr ? -1 : (e[0] == '0' ? 0 : 1);
+  }();
+  if (forced >= 0) return forced == 1;
+  return N >= (k <= 8 ? 24576 : 40960);
+}
+
 struct ScreenLayout {
-  bool big;
-  int Np, Dp, cap;
+  bool big, sym;
+  int Np, Dp, cap_r, cap_c;
   size_t xb, part, tau, cnt, buf, flags, total;
 };
 
@@ -444,13 +514,15 @@ ScreenLayout screen_layout(int64_t N, int64_t D, int k) {
   const int tile = L.big ? Shape<true>::kTile : Shape<false>::kTile;
   L.Np = (int)((N + tile - 1) / tile * tile);
   L.Dp = (int)((D + kSK - 1) / kSK * kSK);
-  L.cap = k <= 8 ? 64 : 128;
+  L.cap_r = k <= 8 ? 64 : 128;  // slots per (query, candidate split) region
+  L.sym = screen_sym(N, k);
+  L.cap_c = L.sym ? kSplits * L.cap_r : 0;  // slots of the column-direction region (triangular sweep only)
   size_t at = 0;
   L.xb = at, at += align256((size_t)L.Np * L.Dp * 2);
   L.part = at, at += align256((size_t)N * Shape<true>::kSubsets * 2 * 4);
   L.tau = at, at += align256((size_t)N * 4);
-  L.cnt = at, at += align256((size_t)N * kSplits * 4);
-  L.buf = at, at += align256((size_t)N * kSplits * L.cap * 8);
+  L.cnt = at, at += align256((size_t)N * (kSplits + 1) * 4);
+  L.buf = at, at += align256((size_t)N * (kSplits * L.cap_r + L.cap_c) * 8);
   L.flags = at, at += align256((size_t)N * 4);
   L.total = at;
   return L;
@@ -461,7 +533,7 @@ hipError_t launch_screen(const ScreenArgs& a, int64_t N, int k, hipStream_t s) {
   using S = Shape<BIG>;
   const int n_groups = (a.Np / S::kTile + 7) / 8;
   const unsigned blocks = (unsigned)(8 * ((n_groups + 7) / 8) * 64);
-  const size_t lds_sample = 2 * S::kStage, lds_emit = 2 * S::kStage + S::kTile * 4;
+  const size_t lds_sample = 2 * S::kStage, lds_emit = 2 * S::kStage + 2 * S::kTile * 4;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<false, BIG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sample);
   if (err != hipSuccess) return err;
@@ -471,6 +543,8 @@ hipError_t launch_screen(const ScreenArgs& a, int64_t N, int k, hipStream_t s) {
   hipLaunchKernelGGL((knn_screen_kernel<false, BIG>), dim3(blocks), dim3(S::kThreads), lds_sample, s, a);
   hipLaunchKernelGGL((knn_tau_kernel<S::kSubsets * 2 / 64>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a.part_val, (int)N, k,
                      const_cast<float*>(a.tau0));
+  err = hipMemsetAsync(a.cnt, 0, (size_t)N * (kSplits + 1) * 4, s);
+  if (err != hipSuccess) return err;
   hipLaunchKernelGGL((knn_screen_kernel<true, BIG>), dim3(blocks), dim3(S::kThreads), lds_emit, s, a);
   return hipGetLastError();
 }
@@ -506,15 +580,20 @@ hipError_t knn_cosine_topk_screened(const float* Xn, int64_t ld, int64_t N, int6
                      L.Dp);
 
   ScreenArgs a;
-  a.Xb = Xb, a.N = (int)N, a.Np = L.Np, a.Dp = L.Dp, a.k = k, a.cap = L.cap;
+  a.Xb = Xb, a.N = (int)N, a.Np = L.Np, a.Dp = L.Dp, a.k = k, a.cap_r = L.cap_r, a.cap_c = L.cap_c;
   a.part_val = part, a.tau0 = tau0, a.cnt = cnt, a.buf = buf;
+  a.sym = L.sym ? 1 : 0;
   hipError_t err = L.big ? launch_screen<true>(a, N, k, s) : launch_screen<false>(a, N, k, s);
   if (err != hipSuccess) return err;
   const dim3 rgrid((unsigned)((N + 3) / 4));
-  if (L.cap == 64)
-    hipLaunchKernelGGL(knn_rescore_kernel<8>, rgrid, dim3(256), 0, s, Xn, ld, (int)N, (int)D, k, L.cap, cnt, buf, nbr, flags);
-  else
-    hipLaunchKernelGGL(knn_rescore_kernel<16>, rgrid, dim3(256), 0, s, Xn, ld, (int)N, (int)D, k, L.cap, cnt, buf, nbr, flags);
+#define DGMI_RESCORE(J) \
+  hipLaunchKernelGGL(knn_rescore_kernel<J>, rgrid, dim3(256), 0, s, Xn, ld, (int)N, (int)D, k, L.cap_r, L.cap_c, cnt, buf, nbr, flags)
+  switch ((kSplits * L.cap_r + L.cap_c) / 64) {  // buffer slots per lane
+    case 8: DGMI_RESCORE(8); break;
+    case 16: DGMI_RESCORE(16); break;
+    default: DGMI_RESCORE(32); break;
+  }
+#undef DGMI_RESCORE
   err = hipGetLastError();
   if (err != hipSuccess) return err;
   return knn_cosine_topk_exact_tiles(Xn, ld, N, D, k, nbr, flags, s);

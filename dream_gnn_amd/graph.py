@@ -612,7 +612,7 @@ def feature_similarity_graph(features: torch.Tensor, k: int, symm: bool = True,
     from embeddings; the N x N similarity matrix is never materialised.  On the GPU the neighbour
     search is ``ops.knn_cosine_topk`` when the shape fits it (D % 8 == 0, k <= 16 — the reference runs
     k = 4 on 768-d embeddings, train.py:423): fp32-MFMA tiles + on-chip top-k at the reference's sizes,
-    a bf16-MFMA screen with exact fp32 rescoring from 1536 rows (1.5x / 8.6x the torch path at
+    a bf16-MFMA screen with exact fp32 rescoring from 1536 rows (1.5x / 13x the torch path at
     N = 763 / 100 000); otherwise, or with ``fused=False``, a row-blocked torch GEMM +
     top-k (an 8192-row block against 100k columns is 3.3 GB of fp32, reduced to k ids per row at
     once).  ``fused=True`` insists on the kernel."""

@@ -299,7 +299,7 @@ DGMI_API int dgmi_random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed,
  * dgmi_knn_cosine_supported: 1 if the shape fits the kernel (D % 8 == 0, k <= 16, k <= N, the 32-query
  * tile + lists within LDS: D <= 1024 for k <= 4, D <= 896 for k = 16); callers fall back otherwise.
  * workspace: dgmi_knn_cosine_workspace_bytes(N, D, k) bytes of device scratch (small N: partial lists of the
- * candidate splits; N >= 1536: the bf16 copy + 4 KiB (k <= 8) or 8 KiB of screened candidates per row).
+ * candidate splits; N >= 1536: the bf16 copy + 4-16 KiB of screened candidates per row).
  */
 DGMI_API int dgmi_knn_cosine_supported(int64_t N, int64_t D, int64_t k);
 DGMI_API size_t dgmi_knn_cosine_workspace_bytes(int64_t N, int64_t D, int32_t k);
