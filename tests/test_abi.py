@@ -87,6 +87,23 @@ def test_argument_validation_returns_codes_without_a_gpu():
     assert L.dgmi_gather_concat_f32(None, None, 0, None, 4, 4, None, 4, 4, None, 8, None) == 0
     assert L.dgmi_gather_f32(None, None, -3, None, None) == -1
     assert L.dgmi_gather_f32(None, None, 0, None, None) == 0
+    # sliced product: column_passes is 0 (by footprint) or 1 (one full-width pass)
+    assert L.dgmi_spmm_sliced_f32(16, 16, None, *K0, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 2, 48, 1 << 20, *E0, None) == -1
+    assert L.dgmi_spmm_sliced_f32(16, 16, None, *K0, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 1, 48, 0, *E0, None) == -3  # planes too small
+    # (f4) cosine kNN: shapes the kernels take, workspace sizing, argument checks — host arithmetic only
+    assert L.dgmi_knn_cosine_supported(763, 768, 4) == 1 and L.dgmi_knn_cosine_supported(100_000, 768, 16) == 1
+    assert L.dgmi_knn_cosine_supported(763, 770, 4) == 0    # D % 8
+    assert L.dgmi_knn_cosine_supported(763, 768, 17) == 0   # k > 16
+    assert L.dgmi_knn_cosine_supported(3, 768, 4) == 0      # k > N
+    assert L.dgmi_knn_cosine_supported(763, 2048, 4) == 0   # a 32-query tile of 2048 columns does not fit the LDS
+    small, mid, big = (L.dgmi_knn_cosine_workspace_bytes(n, 768, 4) for n in (763, 8192, 100_000))
+    assert 0 < small < mid < big and big >= 100_000 * (768 * 2 + 16 * 64 * 8)  # bf16 copy + 16 regions of 64 slots
+    assert L.dgmi_knn_cosine_workspace_bytes(763, 770, 4) == 0
+    assert L.dgmi_knn_cosine_topk_f32(None, 768, 0, 768, 4, None, None, 0, None) == 0           # empty problem
+    assert L.dgmi_knn_cosine_topk_f32(None, 768, 763, 768, 4, None, None, 0, None) == -1        # null pointers
+    assert L.dgmi_knn_cosine_topk_f32(16, 760, 763, 768, 4, 16, None, 0, None) == -1            # ld < D
+    assert L.dgmi_knn_cosine_topk_f32(16, 768, 763, 768, 17, 16, None, 0, None) == -1           # unsupported k
+    assert L.dgmi_knn_cosine_topk_f32(16, 768, 763, 768, 4, 16, None, 0, None) == -3            # workspace missing
 
 
 def test_torch_operator_library_is_registered():
