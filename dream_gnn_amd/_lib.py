@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgmi.so")
 TORCH_LIB_PATH = os.path.join(_HERE, "libdgmi_torch.so")  # the dreamgnn_mi::* dispatcher ops over the C ABI
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # name -> (restype, argtypes); mirrors include/dgmi.h one to one.
 _vp = ctypes.c_void_p
@@ -33,6 +33,8 @@ SIGNATURES = {
     "dgmi_gather_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "dgmi_gather_concat_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "dgmi_csr_sliced_from_coo_i32": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, ctypes.c_int32, _vp, _vp, _vp, _vp,
+                                                    ctypes.POINTER(ctypes.c_size_t), _vp]),
+    "dgmi_csr_sliced_from_csr_i32": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, ctypes.c_int32, _vp, _vp, _vp, _vp,
                                                     ctypes.POINTER(ctypes.c_size_t), _vp]),
     "dgmi_spmm_sliced_planes_bytes": (ctypes.c_size_t, [_i64, ctypes.c_int32, _i64]),
     "dgmi_spmm_sliced_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp, _vp, _vp, _i64, _i64,

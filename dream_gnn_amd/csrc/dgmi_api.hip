@@ -200,6 +200,32 @@ DGMI_API int dgmi_csr_sliced_from_coo_i32(const int32_t* row, const int32_t* col
                                                 eid, workspace, workspace_bytes, as_stream(stream)));
 }
 
+DGMI_API int dgmi_csr_sliced_from_csr_i32(const int32_t* indptr, const int32_t* indices, const int32_t* eid, int64_t E,
+                                          int64_t n_rows, int64_t n_cols, int32_t n_slices, int32_t* segptr,
+                                          int32_t* s_indices, int32_t* s_eid, void* workspace, size_t* workspace_bytes,
+                                          dgmi_stream_t stream) {
+  if (E < 0 || n_rows < 0 || n_cols < 0 || n_slices < 1 || n_slices > 64 || workspace_bytes == nullptr)
+    return DGMI_ERR_INVALID_ARG;
+  if (E > INT32_MAX || n_cols >= INT32_MAX || n_rows * (int64_t)n_slices >= INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (workspace != nullptr) {
+    if (segptr == nullptr) return DGMI_ERR_INVALID_ARG;
+    if (E > 0 && (indptr == nullptr || indices == nullptr || eid == nullptr || s_indices == nullptr || s_eid == nullptr))
+      return DGMI_ERR_INVALID_ARG;
+  }
+  const int64_t width = slice_width_for(n_cols, n_slices);
+  size_t need = 0;
+  if (dgmi::csr_sliced_from_csr_i32(indptr, indices, eid, E, n_rows, n_cols, n_slices, width, segptr, s_indices, s_eid,
+                                    nullptr, &need, as_stream(stream)) != hipSuccess)
+    return DGMI_ERR_LAUNCH;
+  if (workspace == nullptr) {
+    *workspace_bytes = need;
+    return DGMI_OK;
+  }
+  if (*workspace_bytes < need) return DGMI_ERR_WORKSPACE;
+  return from_hip(dgmi::csr_sliced_from_csr_i32(indptr, indices, eid, E, n_rows, n_cols, n_slices, width, segptr, s_indices,
+                                                s_eid, workspace, workspace_bytes, as_stream(stream)));
+}
+
 // Destination rows per launch pair: the n_slices partial planes of one chunk stay <= 32 MiB.
 static int64_t sliced_chunk_rows(int64_t n_dst, int32_t n_slices, int64_t F) {
   const int64_t row_bytes = (int64_t)n_slices * ((F + 3) / 4 * 4) * (int64_t)sizeof(float);

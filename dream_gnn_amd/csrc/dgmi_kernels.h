@@ -108,6 +108,12 @@ hipError_t csr_sliced_from_coo_i32(const int32_t* row, const int32_t* col, int64
                                    int32_t* segptr, int32_t* indices, int32_t* eid, void* workspace,
                                    size_t* workspace_bytes, hipStream_t s);
 
+// the same layout from an existing CSR: one partition pass instead of a full sort (dgmi_csr.hip)
+hipError_t csr_sliced_from_csr_i32(const int32_t* indptr, const int32_t* indices, const int32_t* eid, int64_t E,
+                                   int64_t n_rows, int64_t n_cols, int64_t n_slices, int64_t slice_width, int32_t* segptr,
+                                   int32_t* s_indices, int32_t* s_eid, void* workspace, size_t* workspace_bytes,
+                                   hipStream_t s);
+
 struct SlicedArgs {
   const int32_t* segptr;   // n_slices * n_dst + 1
   const int32_t* indices;

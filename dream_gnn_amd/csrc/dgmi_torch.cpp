@@ -197,6 +197,32 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> csr_sliced_from_coo(const Tensor& row
   return {segptr, indices, eid, flag};
 }
 
+std::tuple<Tensor, Tensor, Tensor, Tensor> csr_sliced_from_csr(const Tensor& indptr, const Tensor& indices, const Tensor& eid,
+                                                               int64_t n_cols, int64_t n_slices) {
+  check(indptr, at::kInt, 1, "indptr", indptr);
+  check(indices, at::kInt, 1, "indices", indptr);
+  check(eid, at::kInt, 1, "eid", indptr);
+  TORCH_CHECK(indices.numel() == eid.numel(), "indices/eid length mismatch");
+  TORCH_CHECK(indptr.numel() >= 1, "indptr is empty");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(indptr.device());
+  const int64_t E = indices.numel(), n_rows = indptr.numel() - 1;
+  Tensor segptr = at::empty({n_slices * n_rows + 1}, indptr.options()), s_indices = at::empty({E}, indptr.options()),
+         s_eid = at::empty({E}, indptr.options());
+  size_t need = 0;
+  check_status(dgmi_csr_sliced_from_csr_i32(nullptr, nullptr, nullptr, E, n_rows, n_cols, (int32_t)n_slices, nullptr, nullptr,
+                                            nullptr, nullptr, &need, nullptr),
+               "dgmi_csr_sliced_from_csr_i32(size query)");
+  Tensor ws = scratch(indptr, need < 256 ? 256 : need, kBuilder);
+  size_t have = (size_t)ws.numel();
+  check_status(dgmi_csr_sliced_from_csr_i32(indptr.data_ptr<int32_t>(), indices.data_ptr<int32_t>(), eid.data_ptr<int32_t>(), E,
+                                            n_rows, n_cols, (int32_t)n_slices, segptr.data_ptr<int32_t>(),
+                                            s_indices.data_ptr<int32_t>(), s_eid.data_ptr<int32_t>(), ws.data_ptr(), &have,
+                                            stream_of(indptr)),
+               "dgmi_csr_sliced_from_csr_i32");
+  Tensor flag = ws.narrow(0, 0, 4).view(at::kInt).clone();
+  return {segptr, s_indices, s_eid, flag};
+}
+
 Tensor plan_build(const Tensor& indptr, int64_t nnz, int64_t chunk) {
   check(indptr, at::kInt, 1, "indptr", indptr);
   c10::hip::HIPGuardMasqueradingAsCUDA guard(indptr.device());
@@ -476,6 +502,7 @@ Tensor spmm_csr_autograd(const Tensor& indptr, const Tensor& indices, const OptT
 TORCH_LIBRARY(dreamgnn_mi, m) {
   m.def("csr_from_coo(Tensor row, Tensor col, int n_rows, int n_cols=0) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("csr_sliced_from_coo(Tensor row, Tensor col, int n_rows, int n_cols, int n_slices) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("csr_sliced_from_csr(Tensor indptr, Tensor indices, Tensor eid, int n_cols, int n_slices) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("plan_build(Tensor indptr, int nnz, int chunk) -> Tensor");
   m.def("spmm_csr(Tensor indptr, Tensor indices, Tensor? vals, Tensor X, Tensor? src_scale=None, Tensor? dst_scale=None) -> Tensor");
   m.def("spmm_csr_raw(Tensor indptr, Tensor indices, Tensor? vals, Tensor? eid, Tensor? keep, Tensor X, Tensor? src_scale, "
@@ -503,6 +530,7 @@ TORCH_LIBRARY(dreamgnn_mi, m) {
 TORCH_LIBRARY_IMPL(dreamgnn_mi, CUDA, m) {
   m.impl("csr_from_coo", csr_from_coo);
   m.impl("csr_sliced_from_coo", csr_sliced_from_coo);
+  m.impl("csr_sliced_from_csr", csr_sliced_from_csr);
   m.impl("plan_build", plan_build);
   m.impl("spmm_csr", spmm_csr_forward);
   m.impl("spmm_csr_raw", spmm_csr_new);

@@ -196,6 +196,17 @@ class SlicedCSR:
                                                                                     self.n_slices)
         self.vals = None if vals is None else gather_f32(vals, self.eid)
 
+    @classmethod
+    def from_csr(cls, indptr, indices, eid, n_dst, n_src, n_slices: int = N_SLICES):
+        """The same layout derived from the CSR of the same edge list (``dgmi_csr_sliced_from_csr_i32``): one
+        stable partition pass by source slice instead of a full sort; bit-identical to the constructor."""
+        self = cls.__new__(cls)
+        self.n_dst, self.n_src, self.n_slices = int(n_dst), int(n_src), int(n_slices)
+        self.segptr, self.indices, self.eid, self.range_flag = _T.csr_sliced_from_csr(indptr, indices, eid, self.n_src,
+                                                                                    self.n_slices)
+        self.vals = None
+        return self
+
     _DEFAULT = object()
 
     def spmm(self, X, src_scale=None, dst_scale=None, out=None, vals=_DEFAULT, keep=None, epi=None, full_width=False):
@@ -534,7 +545,7 @@ class CSRGraph:
             return self._dense_product(False, X, src_scale, dst_scale, out, epi)
         if X.dim() == 2 and self._use_sliced(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
             if S.sliced is None:
-                S.sliced = SlicedCSR(S.dst, S.src, S.n_dst, S.n_src)
+                S.sliced = SlicedCSR.from_csr(S.indptr, S.indices, S.eid, S.n_dst, S.n_src)  # one partition pass, no sort
             return S.sliced.spmm(X, src_scale, dst_scale, out, vals=self._vals_for("sliced", S.sliced.eid), keep=self._keep,
                                  epi=epi)
         if X.dim() == 2 and self._use_split(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
@@ -557,7 +568,7 @@ class CSRGraph:
             S.regular_t = self._is_regular(max_deg, self.nnz, S.n_src)
         if dY.dim() == 2 and self._use_sliced(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):
             if S.sliced_t is None:
-                S.sliced_t = SlicedCSR(S.src, S.dst, S.n_src, S.n_dst)
+                S.sliced_t = SlicedCSR.from_csr(indptr_t, indices_t, eid_t, S.n_src, S.n_dst)
             return S.sliced_t.spmm(dY, dst_scale, src_scale, out, vals=self._vals_for("sliced_t", S.sliced_t.eid),
                                    keep=self._keep)
         if dY.dim() == 2 and self._use_split(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):

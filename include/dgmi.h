@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 14
+#define DGMI_ABI_VERSION 15
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -205,6 +205,13 @@ DGMI_API int dgmi_csr_sliced_from_coo_i32(const int32_t* row, const int32_t* col
                                           int32_t* segptr, int32_t* indices, int32_t* eid,
                                           void* workspace, size_t* workspace_bytes,
                                           dgmi_stream_t stream);
+/* The same layout from a CSR that dgmi_csr_from_coo_i32 built (indptr, indices, eid of E entries): one
+ * stable partition pass by source slice instead of a full sort — the CSR is already in (row, input)
+ * order.  Bit-identical output; same workspace protocol and error flag (an out-of-range source id). */
+DGMI_API int dgmi_csr_sliced_from_csr_i32(const int32_t* indptr, const int32_t* indices, const int32_t* eid,
+                                          int64_t E, int64_t n_rows, int64_t n_cols, int32_t n_slices,
+                                          int32_t* segptr, int32_t* sliced_indices, int32_t* sliced_eid,
+                                          void* workspace, size_t* workspace_bytes, dgmi_stream_t stream);
 DGMI_API size_t dgmi_spmm_sliced_planes_bytes(int64_t n_dst, int32_t n_slices, int64_t F);
 DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices, const float* vals,
                                   const int32_t* eid, const uint32_t* keep, int32_t n_keep,

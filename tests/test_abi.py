@@ -16,7 +16,7 @@ def _declared():
 
 
 def test_header_declares_the_expected_entry_points():
-    assert _declared() == ["dgmi_abi_version", "dgmi_csr_from_coo_i32", "dgmi_csr_sliced_from_coo_i32",
+    assert _declared() == ["dgmi_abi_version", "dgmi_csr_from_coo_i32", "dgmi_csr_sliced_from_coo_i32", "dgmi_csr_sliced_from_csr_i32",
                            "dgmi_device_ok", "dgmi_epilogue_backward_f32", "dgmi_gather_add_f32", "dgmi_gather_concat_f32",
                            "dgmi_gather_f32", "dgmi_keep_mask_f32", "dgmi_knn_cosine_supported", "dgmi_knn_cosine_topk_f32",
                            "dgmi_knn_cosine_workspace_bytes",
@@ -115,7 +115,7 @@ def test_torch_operator_library_is_registered():
 
     assert os.path.exists(_lib.TORCH_LIB_PATH)
     for name in ("csr_from_coo", "csr_sliced_from_coo", "plan_build", "spmm_csr", "spmm_csr_raw", "spmm_csr_out",
-                 "spmm_sliced_raw", "spmm_sliced_out", "epilogue_backward", "knn_cosine_topk", "gather_f32", "gather_concat_raw", "gather_add_raw",
+                 "spmm_sliced_raw", "spmm_sliced_out", "csr_sliced_from_csr", "epilogue_backward", "knn_cosine_topk", "gather_f32", "gather_concat_raw", "gather_add_raw",
                  "random_subset_select", "random_subset_select_batch", "keep_mask"):
         assert hasattr(torch.ops.dreamgnn_mi, name), name
     schema = torch.ops.dreamgnn_mi.spmm_csr.default._schema

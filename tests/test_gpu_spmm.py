@@ -313,6 +313,29 @@ def test_xcd_sliced_column_passes(oracle, dev, F, mode):
     assert np.abs(y - y64).max() <= RTOL * np.abs(y64).max()
 
 
+@pytest.mark.parametrize("n_slices", [8, 3, 1])
+@pytest.mark.parametrize("shape", [(203, 157, 7000), (5, 3, 0), (9, 5, 5300), (4000, 70001, 90000)])
+def test_sliced_layout_from_csr_is_bit_identical(oracle, dev, shape, n_slices):
+    """(f1) `dgmi_csr_sliced_from_csr_i32`: the sliced layout derived from the CSR by one stable partition
+    pass == the layout sorted from the COO list == its numpy restatement, bit for bit (segptr, indices, eid)."""
+    from dream_gnn_amd import ops
+
+    n_dst, n_src, E = shape
+    rng = np.random.default_rng(n_dst + n_slices)
+    dst, src = _rand_graph(rng, n_dst, n_src, E) if E else (np.zeros(0, np.int32), np.zeros(0, np.int32))
+    if E:
+        dst[: E // 3] = 2  # one long row
+    d, s_ = torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev)
+    indptr, indices, eid, _ = ops.csr_from_coo(d, s_, n_dst, n_src, return_flag=True)
+    a = ops.SlicedCSR(d, s_, n_dst, n_src, n_slices=n_slices)
+    b = ops.SlicedCSR.from_csr(indptr, indices, eid, n_dst, n_src, n_slices=n_slices)
+    assert torch.equal(a.segptr, b.segptr) and torch.equal(a.indices, b.indices) and torch.equal(a.eid, b.eid)
+    assert int(b.range_flag) == 0
+    segptr, idx, e = oracle.csr_sliced_from_coo(dst, src, n_dst, n_src, n_slices)
+    assert np.array_equal(b.segptr.cpu().numpy(), segptr) and np.array_equal(b.indices.cpu().numpy(), idx)
+    assert np.array_equal(b.eid.cpu().numpy(), e)
+
+
 def test_xcd_sliced_edge_cases(oracle, dev):
     from dream_gnn_amd import ops
 
