@@ -31,7 +31,11 @@ __device__ __forceinline__ void store_plane_row(float* p, const float4& v) {
   // one streaming 16-B store: the planes are write-once / read-once; keep them from evicting
   // the XCD's slice of X out of L2
   v4f t = {v.x, v.y, v.z, v.w};
+#ifdef DGMI_PLANES_REGULAR_STORE  // A/B switch: ordinary stores run the step in 3.03 ms instead of 2.85 ms
+  *reinterpret_cast<v4f*>(p) = t;
+#else
   __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+#endif
 }
 
 // A (row, slice) segment is short (deg / n_slices: 12-25 edges at config 4).  In the slice-major
