@@ -202,7 +202,10 @@ __global__ __launch_bounds__(256) void reduce_planes_kernel(const float* __restr
     if (S > 0) {
       float4 v[S > 0 ? S : 1];
 #pragma unroll
-      for (int s = 0; s < S; ++s) v[s] = *reinterpret_cast<const float4*>(p + s * plane_stride);
+      for (int s = 0; s < S; ++s) {
+        const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p + s * plane_stride));
+        v[s] = make_float4(t.x, t.y, t.z, t.w);
+      }
       acc = v[0];
 #pragma unroll
       for (int s = 1; s < S; ++s) {
