@@ -171,6 +171,9 @@ hipError_t gather_f32(const float* in, const int32_t* perm, int64_t n, float* ou
 bool knn_supported(int64_t N, int64_t D, int64_t k);
 size_t knn_workspace_bytes(int64_t N, int64_t D, int k);  // small N: partial lists of the candidate splits; large N: the screen's buffers
 // large N (dgmi_knn_screen.hip): bf16-MFMA screen + exact fp32 rescoring; flagged tiles recomputed by the fp32 kernel
+constexpr int kKnnTileMaxK = 16;    // fp32 tile kernel: per-lane lists in LDS
+constexpr int kKnnScreenMaxK = 64;  // bf16 screen: a wave's lanes hold the top-k
+int64_t knn_screen_min_rows();
 bool knn_screen_supported(int64_t N, int64_t D, int64_t k);
 size_t knn_screen_workspace_bytes(int64_t N, int64_t D, int k);
 hipError_t knn_cosine_topk_screened(const float* Xn, int64_t ld, int64_t N, int64_t D, int k, int32_t* nbr, void* workspace,

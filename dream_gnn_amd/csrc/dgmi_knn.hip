@@ -197,7 +197,11 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const float* __restrict_
 size_t knn_lds_bytes(int64_t D, int k) { return (size_t)(kQ * (D + kPad) + kThreads * k * 2) * 4; }
 
 bool knn_supported(int64_t N, int64_t D, int64_t k) {
-  return N >= 1 && D >= 8 && D % 8 == 0 && k >= 1 && k <= kMaxK && k <= N && knn_lds_bytes(D, (int)k) <= 160 * 1024 - 1024;
+  if (N < 1 || D < 8 || D % 8 != 0 || k < 1 || k > N) return false;
+  if (k <= kMaxK) return knn_lds_bytes(D, (int)k) <= 160 * 1024 - 1024;  // the tile kernel (alone, or behind the screen)
+  // 16 < k <= 64: only through the bf16 screen (this kernel's lists would not fit the LDS); its take-over is
+  // knn_exact_rows_kernel
+  return k <= kKnnScreenMaxK && D <= 1024 && N >= knn_screen_min_rows();
 }
 
 // candidate splits: enough workgroups for ~2 per CU when N / 32 alone gives fewer, each wave >= 1 tile

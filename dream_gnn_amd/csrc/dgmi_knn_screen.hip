@@ -12,10 +12,10 @@
 //
 // Pipeline (all on one stream, no host round trip):
 //   1. knn_to_bf16_kernel        Xn -> bf16 copy, rows / columns zero-padded to 128 / 64
-//   2. knn_screen_kernel<SAMPLE> every 8th candidate tile: each lane keeps the TWO largest approx scores of the
-//                                candidates it sees for its query (registers; 32 disjoint subsets per query)
-//      knn_tau_kernel            tau'(q) = k-th largest of those 64 scores of 64 distinct candidates: k
-//                                candidates reach it, so it is a lower bound of tau (k <= 16 < 64)
+//   2. knn_screen_kernel<SAMPLE> every 8th candidate tile: each lane keeps the FOUR largest approx scores of the
+//                                candidates it sees for its query (registers; 32 / 64 disjoint subsets per query)
+//      knn_tau_kernel            tau'(q) = k-th largest of those 128 / 256 scores of distinct candidates: k
+//                                candidates reach it, so it is a lower bound of tau (k <= 64)
 //   3. knn_screen_kernel<EMIT>   every pair with approx >= tau' - 2 eps is appended to the query's buffer
 //                                (one global counter per query; order irrelevant).  The similarity matrix is
 //                                symmetric, so only tile pairs (i, j >= i) are multiplied: a score is offered
@@ -93,7 +93,7 @@ struct ScreenArgs {
   const uint16_t* Xb;  // [Np][Dp] bf16
   int N, Np, Dp, k;       // Np: N rounded up to the tile
   int cap_r, cap_c;       // slots of one row-direction region / of the column-direction region of a query's buffer
-  float* part_val;     // SAMPLE: [N][subsets][2] the two largest approx scores of each subset (kUnset: none)
+  float* part_val;     // SAMPLE: [N][subsets][4] the four largest approx scores of each subset (kUnset: none)
   const float* tau0;   // EMIT: [N] lower bound of the k-th largest approx score
   // EMIT: a query's buffer = kSplits regions of cap_r slots, one per candidate split (filled by the one workgroup
   // that owns (query tile, split): LDS counters, count written at the end) + one region of cap_c slots for the
@@ -153,9 +153,9 @@ __global__ __launch_bounds__(Shape<BIG>::kThreads, 2) void knn_screen_kernel(Scr
   for (int ks = 0; ks < 4; ++ks) rd_slot[ks] = ((2 * ks + h) ^ swz) << 4;
   const int a_base = (wc * 64) * 128 + rd_row, b_base = (kT + wq * 32 * QS) * 128 + rd_row;
 
-  float max1[QS], max2[QS], ethr[QS];
+  float top[QS][4], ethr[QS];  // top[qs][0] >= ... >= top[qs][3]
 #pragma unroll
-  for (int qs = 0; qs < QS; ++qs) max1[qs] = max2[qs] = kUnset, ethr[qs] = 4.0f;
+  for (int qs = 0; qs < QS; ++qs) top[qs][0] = top[qs][1] = top[qs][2] = top[qs][3] = kUnset, ethr[qs] = 4.0f;
   if (EMIT) {
     if (tid < kT) cnt_sh[tid] = 0;
 #pragma unroll
@@ -314,14 +314,16 @@ __global__ __launch_bounds__(Shape<BIG>::kThreads, 2) void knn_screen_kernel(Scr
                 }
             }
           }
-        } else if (mx > max2[qs]) {
+        } else if (mx > top[qs][3]) {
 #pragma unroll
           for (int cs = 0; cs < 2; ++cs)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
               const float s = acc[qs][cs][v];
-              max2[qs] = fmaxf(max2[qs], fminf(max1[qs], s));  // branch-free top-2 update
-              max1[qs] = fmaxf(max1[qs], s);
+              top[qs][3] = fmaxf(top[qs][3], fminf(top[qs][2], s));  // branch-free sorted insert, lowest first
+              top[qs][2] = fmaxf(top[qs][2], fminf(top[qs][1], s));
+              top[qs][1] = fmaxf(top[qs][1], fminf(top[qs][0], s));
+              top[qs][0] = fmaxf(top[qs][0], s);
             }
         }
       }
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(Shape<BIG>::kThreads, 2) void knn_screen_kernel(Scr
     for (int qs = 0; qs < QS; ++qs) {
       const int qg = q_wave + qs * 32 + r;
       if (qg < a.N)
-        *reinterpret_cast<float2*>(a.part_val + ((int64_t)qg * S::kSubsets + (split * S::kWC + wc) * 2 + h) * 2) =
-            make_float2(max1[qs], max2[qs]);
+        *reinterpret_cast<float4*>(a.part_val + ((int64_t)qg * S::kSubsets + (split * S::kWC + wc) * 2 + h) * 4) =
+            make_float4(top[qs][0], top[qs][1], top[qs][2], top[qs][3]);
     }
   }
 }
@@ -385,7 +387,7 @@ __device__ __forceinline__ float wave_kth_largest(float (&v)[J], int k, int lane
   return m;
 }
 
-// tau0[q] = k-th largest of the sample scores (top two of each subset: 64 or 128 values) of query q, one wave per query
+// tau0[q] = k-th largest of the sample scores (top four of each subset: 128 or 256 values) of query q, one wave per query
 template <int J>
 __global__ __launch_bounds__(256) void knn_tau_kernel(const float* __restrict__ part_val, int N, int k, float* __restrict__ tau0) {
   const int lane = threadIdx.x & 63, q = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -395,6 +397,63 @@ __global__ __launch_bounds__(256) void knn_tau_kernel(const float* __restrict__ 
   for (int i = 0; i < J; ++i) v[i] = part_val[(int64_t)q * (64 * J) + lane + 64 * i];
   const float t = wave_kth_largest<J>(v, k, lane);
   if (lane == 0) tau0[q] = t;
+}
+
+// k-th largest of the values v[0..J) held per lane across the wave, by bisection on the order-preserving integer
+// image of the floats (32 counting rounds whatever k is; the extraction above costs k rounds).  Needs >= k values.
+template <int J>
+__device__ __forceinline__ float wave_kth_largest_bisect(const float (&v)[J], int k) {
+  uint32_t key[J];
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+    const uint32_t u = __float_as_uint(v[i]);
+    key[i] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  }
+  uint32_t prefix = 0;
+  for (int bit = 31; bit >= 0; --bit) {  // the largest t with #{key >= t} >= k is the k-th largest key
+    const uint32_t trial = prefix | (1u << bit);
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < J; ++i) c += key[i] >= trial ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (c >= k) prefix = trial;
+  }
+  const uint32_t u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
+  return __uint_as_float(u);
+}
+
+// A wave's running top-k: lane i < k holds the i-th best (score desc, id asc).  Every lane passes the same (s, cid).
+__device__ __forceinline__ void wave_topk_insert(float& best_s, int32_t& best_id, float s, int32_t cid, int k, int lane) {
+  const bool better = best_s > s || (best_s == s && best_id < cid);
+  const int pos = __popcll(__ballot(better && lane < k));
+  const float up_s = __shfl_up(best_s, 1);
+  const int32_t up_id = __shfl_up(best_id, 1);
+  if (lane < k && lane > pos) {
+    best_s = up_s;
+    best_id = up_id;
+  } else if (lane == pos && pos < k) {
+    best_s = s;
+    best_id = cid;
+  }
+}
+
+// exact <Xn[q], Xn[c]>: 16 B per lane per 256 columns (qv: the query row, held the same way), fixed reduction tree
+__device__ __forceinline__ float wave_dot(const float4 (&qv)[4], const float* __restrict__ crow_, int d4, int lane) {
+  const float4* crow = reinterpret_cast<const float4*>(crow_);
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (lane + 64 * u < d4) {
+      const float4 c = crow[lane + 64 * u];
+      s = fmaf(qv[u].x, c.x, s);
+      s = fmaf(qv[u].y, c.y, s);
+      s = fmaf(qv[u].z, c.z, s);
+      s = fmaf(qv[u].w, c.w, s);
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);  // the same sum on every lane
+  return s;
 }
 
 // One wave per query: exact top-k among the screened candidates.  kJ = buffer slots per lane
@@ -429,7 +488,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
     return;
   }
   if (lane == 0) flags[q] = 0;
-  const float tau = wave_kth_largest<kJ>(work, k, lane);
+  const float tau = kJ >= 32 ? wave_kth_largest_bisect<kJ>(work, k) : wave_kth_largest<kJ>(work, k, lane);
   const float keep_from = tau - 2.f * kScreenEps;
 
   // the query row, 16 B per lane per 256 columns
@@ -448,32 +507,36 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const float* __restric
       const int src = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
       const int32_t cid = __shfl(e_id[i], src);
-      const float4* crow = reinterpret_cast<const float4*>(Xn + (int64_t)cid * ld);
-      float s = 0.f;
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (lane + 64 * u < d4) {
-          const float4 c = crow[lane + 64 * u];
-          s = fmaf(qv[u].x, c.x, s);
-          s = fmaf(qv[u].y, c.y, s);
-          s = fmaf(qv[u].z, c.z, s);
-          s = fmaf(qv[u].w, c.w, s);
-        }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);  // fixed tree: the same sum on every lane
-      const bool better = best_s > s || (best_s == s && best_id < cid);
-      const int pos = __popcll(__ballot(better && lane < k));
-      const float up_s = __shfl_up(best_s, 1);
-      const int32_t up_id = __shfl_up(best_id, 1);
-      if (lane < k && lane > pos) {
-        best_s = up_s;
-        best_id = up_id;
-      } else if (lane == pos && pos < k) {
-        best_s = s;
-        best_id = cid;
-      }
+      const float s = wave_dot(qv, Xn + (int64_t)cid * ld, d4, lane);
+      wave_topk_insert(best_s, best_id, s, cid, k, lane);
     }
   }
+  if (lane < k) nbr[(int64_t)q * k + lane] = best_id;
+}
+
+// Take-over for k > 16 (the fp32 tile kernel keeps its lists in LDS and stops at k = 16): one workgroup per FLAGGED
+// query scores every candidate exactly, a candidate per wave at a time, and merges the four waves' top-k.
+// Unflagged queries' workgroups leave at once.
+__global__ __launch_bounds__(256) void knn_exact_rows_kernel(const float* __restrict__ Xn, int64_t ld, int N, int D, int k,
+                                                             const int32_t* __restrict__ flags, int32_t* __restrict__ nbr) {
+  const int q = (int)blockIdx.x;
+  if (flags[q] == 0) return;
+  __shared__ float m_s[4 * 64];
+  __shared__ int32_t m_id[4 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d4 = D / 4;
+  const float4* qrow = reinterpret_cast<const float4*>(Xn + (int64_t)q * ld);
+  float4 qv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qv[i] = lane + 64 * i < d4 ? qrow[lane + 64 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float best_s = kMasked;
+  int32_t best_id = 0x7fffffff;
+  for (int c = wave; c < N; c += 4) wave_topk_insert(best_s, best_id, wave_dot(qv, Xn + (int64_t)c * ld, d4, lane), c, k, lane);
+  m_s[wave * 64 + lane] = best_s;
+  m_id[wave * 64 + lane] = best_id;
+  __syncthreads();
+  if (wave != 0) return;
+  for (int w = 1; w < 4; ++w)
+    for (int j = 0; j < k; ++j) wave_topk_insert(best_s, best_id, m_s[w * 64 + j], m_id[w * 64 + j], k, lane);
   if (lane < k) nbr[(int64_t)q * k + lane] = best_id;
 }
 
@@ -514,12 +577,12 @@ ScreenLayout screen_layout(int64_t N, int64_t D, int k) {
   const int tile = L.big ? Shape<true>::kTile : Shape<false>::kTile;
   L.Np = (int)((N + tile - 1) / tile * tile);
   L.Dp = (int)((D + kSK - 1) / kSK * kSK);
-  L.cap_r = k <= 8 ? 64 : 128;  // slots per (query, candidate split) region
+  L.cap_r = k <= 8 ? 64 : (k <= 16 ? 128 : 256);  // slots per (query, candidate split) region
   L.sym = screen_sym(N, k);
   L.cap_c = L.sym ? kSplits * L.cap_r : 0;  // slots of the column-direction region (triangular sweep only)
   size_t at = 0;
   L.xb = at, at += align256((size_t)L.Np * L.Dp * 2);
-  L.part = at, at += align256((size_t)N * Shape<true>::kSubsets * 2 * 4);
+  L.part = at, at += align256((size_t)N * Shape<true>::kSubsets * 4 * 4);
   L.tau = at, at += align256((size_t)N * 4);
   L.cnt = at, at += align256((size_t)N * (kSplits + 1) * 4);
   L.buf = at, at += align256((size_t)N * (kSplits * L.cap_r + L.cap_c) * 8);
@@ -541,7 +604,7 @@ hipError_t launch_screen(const ScreenArgs& a, int64_t N, int k, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_emit);
   if (err != hipSuccess) return err;
   hipLaunchKernelGGL((knn_screen_kernel<false, BIG>), dim3(blocks), dim3(S::kThreads), lds_sample, s, a);
-  hipLaunchKernelGGL((knn_tau_kernel<S::kSubsets * 2 / 64>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a.part_val, (int)N, k,
+  hipLaunchKernelGGL((knn_tau_kernel<S::kSubsets * 4 / 64>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a.part_val, (int)N, k,
                      const_cast<float*>(a.tau0));
   err = hipMemsetAsync(a.cnt, 0, (size_t)N * (kSplits + 1) * 4, s);
   if (err != hipSuccess) return err;
@@ -561,6 +624,8 @@ bool knn_screen_supported(int64_t N, int64_t D, int64_t k) {
   }();
   return knn_supported(N, D, k) && N >= min_rows && N < (1 << 30) && D <= 1024;
 }
+
+int64_t knn_screen_min_rows() { return kScreenMinRows; }
 
 size_t knn_screen_workspace_bytes(int64_t N, int64_t D, int k) { return screen_layout(N, D, k).total; }
 
@@ -591,12 +656,15 @@ hipError_t knn_cosine_topk_screened(const float* Xn, int64_t ld, int64_t N, int6
   switch ((kSplits * L.cap_r + L.cap_c) / 64) {  // buffer slots per lane
     case 8: DGMI_RESCORE(8); break;
     case 16: DGMI_RESCORE(16); break;
-    default: DGMI_RESCORE(32); break;
+    case 32: DGMI_RESCORE(32); break;
+    default: DGMI_RESCORE(64); break;
   }
 #undef DGMI_RESCORE
   err = hipGetLastError();
   if (err != hipSuccess) return err;
-  return knn_cosine_topk_exact_tiles(Xn, ld, N, D, k, nbr, flags, s);
+  if (k <= kKnnTileMaxK) return knn_cosine_topk_exact_tiles(Xn, ld, N, D, k, nbr, flags, s);
+  hipLaunchKernelGGL(knn_exact_rows_kernel, dim3((unsigned)N), dim3(256), 0, s, Xn, ld, (int)N, (int)D, k, flags, nbr);
+  return hipGetLastError();
 }
 
 }  // namespace dgmi

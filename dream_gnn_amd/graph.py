@@ -610,7 +610,7 @@ def feature_similarity_graph(features: torch.Tensor, k: int, symm: bool = True,
                              block_rows: int = 8192, fused=None) -> torch.Tensor:
     """``_create_feature_similarity_graph`` (data_loader.py:312-344): cosine-similarity kNN graph
     from embeddings; the N x N similarity matrix is never materialised.  On the GPU the neighbour
-    search is ``ops.knn_cosine_topk`` when the shape fits it (D % 8 == 0, k <= 16 — the reference runs
+    search is ``ops.knn_cosine_topk`` when the shape fits it (D % 8 == 0, k <= 16, or k <= 64 from 1536 rows — the reference runs
     k = 4 on 768-d embeddings, train.py:423): fp32-MFMA tiles + on-chip top-k at the reference's sizes,
     a bf16-MFMA screen with exact fp32 rescoring from 1536 rows (1.5x / 13x the torch path at
     N = 763 / 100 000); otherwise, or with ``fused=False``, a row-blocked torch GEMM +

@@ -303,7 +303,8 @@ DGMI_API int dgmi_random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed,
  * with a rounding bound that provably keeps every member of the fp32 top-k, then rescored in fp32
  * (rows must be unit vectors or zero for that bound).  Ties at the k-th value are broken arbitrarily
  * (upstream too).
- * dgmi_knn_cosine_supported: 1 if the shape fits the kernel (D % 8 == 0, k <= 16, k <= N, the 32-query
+ * dgmi_knn_cosine_supported: 1 if the shape fits the kernels (D % 8 == 0, k <= N, k <= 16 — or k <= 64 when
+ * N >= 1536 and D <= 1024, where the bf16 screen runs and a wave's lanes hold the top-k —, the 32-query
  * tile + lists within LDS: D <= 1024 for k <= 4, D <= 896 for k = 16); callers fall back otherwise.
  * workspace: dgmi_knn_cosine_workspace_bytes(N, D, k) bytes of device scratch (small N: partial lists of the
  * candidate splits; N >= 1536: the bf16 copy + 4-16 KiB of screened candidates per row).

@@ -93,7 +93,8 @@ def test_argument_validation_returns_codes_without_a_gpu():
     # (f4) cosine kNN: shapes the kernels take, workspace sizing, argument checks — host arithmetic only
     assert L.dgmi_knn_cosine_supported(763, 768, 4) == 1 and L.dgmi_knn_cosine_supported(100_000, 768, 16) == 1
     assert L.dgmi_knn_cosine_supported(763, 770, 4) == 0    # D % 8
-    assert L.dgmi_knn_cosine_supported(763, 768, 17) == 0   # k > 16
+    assert L.dgmi_knn_cosine_supported(763, 768, 17) == 0   # k > 16 only through the screen (N >= 1536)
+    assert L.dgmi_knn_cosine_supported(100_000, 768, 64) == 1 and L.dgmi_knn_cosine_supported(100_000, 768, 65) == 0
     assert L.dgmi_knn_cosine_supported(3, 768, 4) == 0      # k > N
     assert L.dgmi_knn_cosine_supported(763, 2048, 4) == 0   # a 32-query tile of 2048 columns does not fit the LDS
     small, mid, big = (L.dgmi_knn_cosine_workspace_bytes(n, 768, 4) for n in (763, 8192, 100_000))
@@ -102,7 +103,7 @@ def test_argument_validation_returns_codes_without_a_gpu():
     assert L.dgmi_knn_cosine_topk_f32(None, 768, 0, 768, 4, None, None, 0, None) == 0           # empty problem
     assert L.dgmi_knn_cosine_topk_f32(None, 768, 763, 768, 4, None, None, 0, None) == -1        # null pointers
     assert L.dgmi_knn_cosine_topk_f32(16, 760, 763, 768, 4, 16, None, 0, None) == -1            # ld < D
-    assert L.dgmi_knn_cosine_topk_f32(16, 768, 763, 768, 17, 16, None, 0, None) == -1           # unsupported k
+    assert L.dgmi_knn_cosine_topk_f32(16, 768, 763, 768, 17, 16, None, 0, None) == -1           # unsupported k at this N
     assert L.dgmi_knn_cosine_topk_f32(16, 768, 763, 768, 4, 16, None, 0, None) == -3            # workspace missing
 
 

@@ -653,7 +653,8 @@ def test_output_epilogue_in_every_kernel_form(dev, F, act, slope):
 
 
 @pytest.mark.parametrize("N,D,k", [(763, 768, 4), (681, 768, 4), (33, 8, 1), (1000, 64, 16), (5000, 768, 8), (32, 1024, 3),
-                                   (97, 24, 13), (1536, 64, 16), (2048, 64, 1), (3001, 40, 2), (16500, 16, 5), (20000, 768, 4), (9001, 200, 16), (50001, 72, 6), (41000, 64, 12), (25000, 136, 3)])
+                                   (97, 24, 13), (1536, 64, 16), (2048, 64, 1), (3001, 40, 2), (16500, 16, 5), (20000, 768, 4), (9001, 200, 16), (50001, 72, 6), (41000, 64, 12), (25000, 136, 3),
+                                   (3000, 64, 64), (30000, 128, 33), (60000, 72, 40)])
 def test_fused_knn_kernel_finds_the_k_most_similar_rows(dev, N, D, k):
     """(f4) `dgmi_knn_cosine_topk_f32` (fp32 MFMA tiles + running top-k on chip) against a brute-force
     float64 similarity matrix: every row's selected neighbours are k distinct valid ids whose
@@ -698,10 +699,13 @@ def test_screened_knn_recomputes_overflowing_rows_exactly(dev):
     are flagged and their tiles recomputed by the fp32 kernel — the answer is still the exact top-k."""
     from dream_gnn_amd import ops
 
-    for N, D, k in ((10000, 128, 4), (30000, 64, 4)):  # full rectangle / triangular sweep (both directions overflow)
+    # full rectangle / triangular sweep (both directions overflow) / k > 16: the exact-row take-over kernel
+    for N, D, k in ((10000, 128, 4), (30000, 64, 4), (9000, 64, 40)):
         gen = torch.Generator().manual_seed(5)
         X = torch.randn(N, D, generator=gen)
         X[3000:3400] = X[3000] + 1e-3 * torch.randn(400, D, generator=gen)
+        if k > 16:  # enough near-duplicates to overflow the wider regions too
+            X[1000:2600] = X[1000] + 1e-3 * torch.randn(1600, D, generator=gen)
         X[N - 700:N - 100] = X[N - 1] + 1e-3 * torch.randn(600, D, generator=gen)
         xn = (X / X.norm(dim=1, keepdim=True)).to(dev)
         nbr = ops.knn_cosine_topk(xn, k).long()

@@ -29,7 +29,7 @@ def torch_path(xn, k, block_rows=8192):
     return out
 
 
-for N, D, k in ((763, 768, 4), (1256, 768, 4), (8192, 768, 4), (20_000, 768, 4), (100_000, 768, 4), (100_000, 768, 16)):
+for N, D, k in ((763, 768, 4), (1256, 768, 4), (8192, 768, 4), (20_000, 768, 4), (100_000, 768, 4), (100_000, 768, 16), (20_000, 768, 64), (100_000, 768, 64)):
     x = torch.randn(N, D, device=dev)
     xn = x / x.norm(dim=1, keepdim=True)
     reps = 20 if N < 5000 else 2
