@@ -36,9 +36,11 @@ bad = 0
 cases = 0
 for N in (1536, 2500, 4097, 9000, 20011, 26000, 45000):
     for D in (8, 64, 200, 768):
-        for k in (1, 4, 16):
+        for k in (1, 4, 16, 33, 64):
             for kind in ("iso", "clustered", "lowrank", "dups", "zeros", "heavy"):
                 if N * D > 20011 * 768 and kind not in ("iso", "clustered"):
+                    continue
+                if not ops.knn_cosine_supported(N, D, k):
                     continue
                 x = data(kind, N, D)
                 nrm = x.norm(dim=1, keepdim=True)
