@@ -38,14 +38,16 @@ __device__ __forceinline__ uint32_t edge_hash(uint64_t seed, uint64_t e) {
   return (uint32_t)(z >> 32);
 }
 
-// Edges outside every segment are kept.
+// Edges outside every segment are kept; an edge covered by several segments (a dropout applied to an
+// already dropped view) survives only if EVERY covering segment keeps it — the intersection, as a
+// chain of independent dropouts composes.
 __device__ __forceinline__ bool edge_kept(const KeepSeg* __restrict__ tab, int n_seg, uint32_t e) {
   for (int k = 0; k < n_seg; ++k) {
     const KeepSeg sg = tab[k];
     if (e >= sg.e_begin && e < sg.e_end) {
       const uint32_t local = e - sg.e_begin;
       const uint32_t h = edge_hash(((uint64_t)sg.seed_hi << 32) | sg.seed_lo, local);
-      return h < sg.thr || (h == sg.thr && (int32_t)local <= sg.tie_cut);
+      if (!(h < sg.thr || (h == sg.thr && (int32_t)local <= sg.tie_cut))) return false;
     }
   }
   return true;

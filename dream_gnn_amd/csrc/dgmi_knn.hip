@@ -234,6 +234,8 @@ hipError_t knn_cosine_topk_exact_tiles(const float* Xn, int64_t ld, int64_t N, i
 hipError_t knn_cosine_topk_f32(const float* Xn, int64_t ld, int64_t N, int64_t D, int k, int32_t* nbr, void* workspace,
                                hipStream_t s) {
   if (knn_screen_supported(N, D, k)) return knn_cosine_topk_screened(Xn, ld, N, D, k, nbr, workspace, s);
+  // the tile kernel keeps per-lane lists of k entries in LDS: never past kKnnTileMaxK, never past the LDS
+  if (k > kKnnTileMaxK || knn_lds_bytes(D, k) > 160 * 1024 - 1024) return hipErrorInvalidValue;
   const size_t lds = knn_lds_bytes(D, k);
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_cosine_topk_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

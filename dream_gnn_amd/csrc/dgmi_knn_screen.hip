@@ -614,18 +614,21 @@ hipError_t launch_screen(const ScreenArgs& a, int64_t N, int k, hipStream_t s) {
 
 }  // namespace
 
-bool knn_screen_supported(int64_t N, int64_t D, int64_t k) {
-  // the rescoring holds a row in 4 float4 per lane; below kScreenMinRows the fp32 kernel alone is faster
-  // (DGMI_KNN_SCREEN_MIN_ROWS overrides the crossover, for tools/knn_bench.py)
+// the crossover to the screen: kScreenMinRows, or DGMI_KNN_SCREEN_MIN_ROWS (tools/knn_bench.py) — ONE value for every
+// caller, so knn_supported() and knn_screen_supported() can never disagree about which kernel takes a shape
+int64_t knn_screen_min_rows() {
   static const int64_t min_rows = [] {
     const char* e = getenv("DGMI_KNN_SCREEN_MIN_ROWS");
     const long long v = e != nullptr ? atoll(e) : 0;
     return (int64_t)(v > 0 ? v : kScreenMinRows);
   }();
-  return knn_supported(N, D, k) && N >= min_rows && N < (1 << 30) && D <= 1024;
+  return min_rows;
 }
 
-int64_t knn_screen_min_rows() { return kScreenMinRows; }
+bool knn_screen_supported(int64_t N, int64_t D, int64_t k) {
+  // the rescoring holds a row in 4 float4 per lane; below the crossover the fp32 kernel alone is faster
+  return knn_supported(N, D, k) && N >= knn_screen_min_rows() && N < (1 << 30) && D <= 1024;
+}
 
 size_t knn_screen_workspace_bytes(int64_t N, int64_t D, int k) { return screen_layout(N, D, k).total; }
 

@@ -370,7 +370,9 @@ Tensor knn_cosine_topk(const Tensor& Xn, int64_t k) {
   c10::hip::HIPGuardMasqueradingAsCUDA guard(x.t.device());
   Tensor nbr = at::empty({x.rows, k}, x.t.options().dtype(at::kInt));
   const size_t wbytes = dgmi_knn_cosine_workspace_bytes(x.rows, x.F, (int32_t)k);
-  Tensor ws = scratch(x.t, wbytes, kBuilder);
+  // per call, from the caching allocator (reused on the same stream, returned by empty_cache()): the screened search
+  // needs 1-3.5 GB at N = 100 000, which a one-off graph construction must not pin for the life of the process
+  Tensor ws = at::empty({(int64_t)(wbytes < 16 ? 16 : wbytes)}, x.t.options().dtype(at::kByte));
   check_status(dgmi_knn_cosine_topk_f32(x.t.data_ptr<float>(), x.ld, x.rows, x.F, (int32_t)k, nbr.data_ptr<int32_t>(),
                                         ws.data_ptr(), (size_t)ws.numel(), stream_of(x.t)), "dgmi_knn_cosine_topk_f32");
   return nbr;

@@ -533,6 +533,17 @@ def random_edge_dropout_sparse(adj, dropout_rate: float = 0.1, generator: Option
         from .layers import adjacency_csr  # local import: layers imports this module
 
         base = adjacency_csr(adj)
+        alive = base.survivors()
+        if alive is not None:
+            # dropout of an already dropped view: the reference builds a new tensor from the survivors and
+            # keeps max(1, int(E' * (1 - p))) of THOSE (augmentation.py:113-124) — an exact count of E', not
+            # an independent subset of the parent's entries.  Rare (one readback), so go through the lists.
+            idx = torch.nonzero(alive, as_tuple=False).reshape(-1)
+            E = int(idx.numel())
+            keep = max(1, int(E * (1 - dropout_rate))) if E else 0
+            perm = torch.randperm(E, device=base.device, generator=generator)[:keep]
+            mask = torch.zeros(base.nnz, dtype=torch.float32, device=base.device).index_fill_(0, idx[perm], 1.0)
+            return base.undropped().masked(mask)
         E = base.nnz
         keep = max(1, int(E * (1 - dropout_rate)))
         keep_idx, desc = _select_kept(E, keep, base.device, generator, selection)
@@ -547,8 +558,13 @@ def random_edge_dropout_sparse(adj, dropout_rate: float = 0.1, generator: Option
     out._dgmi_trusted = True  # a subset of a valid adjacency: adjacency_csr skips the id re-check (no host sync)
     # layers.adjacency_csr applies the dropout as a keep mask over the parent's CSR instead of
     # re-sorting these entries (same multiset of entries, hence the same product)
-    out._dgmi_parent = adj
-    out._dgmi_keep_idx = perm
+    root = getattr(adj, "_dgmi_parent", None)
+    if root is not None:  # a dropout of a dropped tensor: positions are kept relative to the ROOT's entries
+        out._dgmi_parent = root
+        out._dgmi_keep_idx = adj._dgmi_keep_idx[perm]
+    else:
+        out._dgmi_parent = adj
+        out._dgmi_keep_idx = perm
     return out
 
 
@@ -563,6 +579,8 @@ def random_edge_dropout_sparse_views(adjs, dropout_rate: float = 0.1, generator:
         return []
     if bases[0].device.type != "cuda" or (generator is not None and generator.device.type != "cpu"):
         return [random_edge_dropout_sparse(a, dropout_rate, generator, as_view=True) for a in adjs]
+    if any(b.survivors() is not None for b in bases):  # a dropout of dropped views: exact counts of the survivors
+        return [random_edge_dropout_sparse(b, dropout_rate, generator, as_view=True) for b in bases]
     keeps = [max(1, int(b.nnz * (1 - dropout_rate))) for b in bases]
     seeds = [_draw_seed(generator) for _ in bases]
     descs = ops.random_subset_select_batch([b.nnz for b in bases], keeps, seeds, bases[0].device)

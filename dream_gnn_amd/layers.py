@@ -290,8 +290,12 @@ class GCMCLayer(nn.Module):
             return 1, float(a.negative_slope)
         if isinstance(a, nn.ReLU):
             return 1, 0.0
-        if not isinstance(a, nn.Module) and getattr(a, "__name__", "") == "<lambda>" and a(0) == 0 and a(-2.5) == -2.5:
-            return 0, 0.0  # get_activation(None): the identity
+        if not isinstance(a, nn.Module) and getattr(a, "__name__", "") == "<lambda>":
+            try:  # get_activation(None) is `lambda x: x`; any other lambda (e.g. one that needs a Tensor) takes the fallback
+                if a(0) == 0 and a(-2.5) == -2.5:
+                    return 0, 0.0
+            except Exception:
+                return None
         return None
 
     def _fused_conv(self, graph, inputs, mod_args):
@@ -355,7 +359,11 @@ class GCMCLayer(nn.Module):
                 width = weights[cans[0]].shape[1]
                 m = None
                 if p > 0:
-                    m = torch.empty((csr.n_dst, width), dtype=torch.float32, device=inputs[cans[0][0]].device).bernoulli_(1 - p)
+                    # drawn through F.dropout on ones — the very consumer nn.Dropout is in the un-fused path (Philox
+                    # on the GPU, bernoulli_ on the CPU), so fuse_epilogue=True / False see the same masks and leave
+                    # the generator in the same state for the same seed
+                    m = (F.dropout(torch.ones((csr.n_dst, width), dtype=torch.float32, device=inputs[cans[0][0]].device),
+                                   p, True) != 0).to(torch.float32)
                     if -width % 4:
                         m = F.pad(m, (0, -width % 4))
                 masks[nt] = (m, 1.0 / (1.0 - p) if p > 0 else 1.0)

@@ -353,6 +353,7 @@ class CSRGraph:
         self._coo_vals = coo_vals
         self._v = {}  # layout name -> values permuted into that layout
         self._keep = keep  # (n, 8) int32 subset descriptions applied on the fly, or None
+        self._mask = None  # 0/1 keep mask already multiplied into the values by masked(), COO order
 
     def with_values(self, coo_vals: Optional[torch.Tensor]) -> "CSRGraph":
         """A view sharing this graph's structure (and whatever it builds later) with other per-edge
@@ -369,17 +370,27 @@ class CSRGraph:
         keep = keep.to(torch.float32)
         view = self.with_values(keep if self._coo_vals is None else self._coo_vals * keep)
         view._keep = self._keep
+        view._mask = keep if self._mask is None else self._mask * keep
+        view.__dict__["_vals_before_mask"] = self.__dict__.get("_vals_before_mask", self._coo_vals) if self._mask is not None \
+            else self._coo_vals
         return view
 
     def dropped(self, desc: torch.Tensor) -> "CSRGraph":
         """View of the same structure and values with edge dropout applied ON THE FLY: ``desc`` holds
         the 8-word description(s) of the surviving subset(s) (``random_subset_select``), evaluated
         per edge inside the kernels through each layout's ``eid`` — no mask is carried into the
-        layouts, nothing is re-sorted, dropped edges are skipped (not multiplied by zero)."""
+        layouts, nothing is re-sorted, dropped edges are skipped (not multiplied by zero).
+
+        On a view that already carries descriptions the new ones are ANDed in (an edge covered by
+        several descriptions survives only if each keeps it, ``csrc/dgmi_keep.h``): the intersection
+        of independently drawn subsets.  A chained dropout that must keep an EXACT count of the
+        survivors (the reference's composition, augmentation.py:113-124) draws its subset among
+        :meth:`survivors` instead — ``graph.random_edge_dropout_sparse`` does."""
         desc = _prep_keep(desc)
         view = object.__new__(CSRGraph)
         view._S = self._S
         view._coo_vals, view._v = self._coo_vals, self._v  # values (and their per-layout copies) are shared
+        view._mask = self._mask
         view._keep = desc if self._keep is None else torch.cat([self._keep, desc])
         if view._keep.shape[0] > 8:
             raise RuntimeError("at most 8 subset descriptions per graph view")
@@ -388,6 +399,25 @@ class CSRGraph:
     def keep_mask(self) -> Optional[torch.Tensor]:
         """float 0/1 mask over the COO edge order of the on-the-fly dropout (None if there is none)."""
         return None if self._keep is None else keep_mask(self._keep, self.nnz)
+
+    def survivors(self) -> Optional[torch.Tensor]:
+        """float 0/1 mask over the COO edge order of every dropout this view carries — the on-the-fly
+        descriptions and the masks folded into the values by :meth:`masked` — or None for an
+        un-dropped graph."""
+        m = self.keep_mask()
+        if self._mask is not None:
+            m = self._mask if m is None else m * self._mask
+        return m
+
+    def undropped(self) -> "CSRGraph":
+        """The view of the same structure with every dropout removed (original values)."""
+        view = object.__new__(CSRGraph)
+        view._S = self._S
+        vals = self._coo_vals
+        if self._mask is not None:
+            vals = self.__dict__.get("_vals_before_mask")
+        view._set_values(vals)
+        return view
 
     def _vals_for(self, layout: str, eid: torch.Tensor):
         if self._coo_vals is None:

@@ -282,10 +282,10 @@ def random_subset_select(E, keep, seed, e_offset=0):
 
 def keep_mask(desc, E):
     """Restatement of ``dgmi_keep_mask_f32``: float 0/1 over edges [0, E) under (n, 8) descriptions;
-    edges outside every description are kept."""
+    edges outside every description are kept, an edge covered by several descriptions survives only
+    if every one of them keeps it (csrc/dgmi_keep.h edge_kept)."""
     d = np.asarray(desc, np.int32).reshape(-1, 8).view(np.uint32).astype(np.uint64)
     mask = np.ones(E, np.float32)
-    claimed = np.zeros(E, bool)
     for e_begin, e_end, lo, hi, thr, cut, _, _ in d:
         e_begin, e_end = int(e_begin), min(int(e_end), E)
         if e_end <= e_begin:
@@ -294,9 +294,7 @@ def keep_mask(desc, E):
         h = _edge_hash((int(hi) << 32) | int(lo), n)
         cut = int(np.uint32(cut).view(np.int32)) if isinstance(cut, np.generic) else int(np.array(cut, np.uint32).view(np.int32))
         kept = (h < thr) | ((h == thr) & (np.arange(n) <= cut))
-        sel = ~claimed[e_begin:e_end]  # first matching description wins, as in the kernel
-        mask[e_begin:e_end][sel] = kept[sel].astype(np.float32)
-        claimed[e_begin:e_end] = True
+        mask[e_begin:e_end] *= kept.astype(np.float32)  # intersection over the covering descriptions
     return mask
 
 

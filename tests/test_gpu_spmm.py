@@ -511,6 +511,11 @@ def test_random_subset_description_bit_exact(oracle, dev, E, keep, off):
     b = ops.random_subset_select(E, keep, 6, dev, e_offset=E)
     both = ops.keep_mask(torch.stack([a, b]), 2 * E).cpu().numpy()
     assert np.array_equal(both, np.concatenate([oracle.random_subset_mask(E, keep, 5), oracle.random_subset_mask(E, keep, 6)]))
+    # two descriptions over the SAME edges (a dropout of a dropped view): an edge survives only if both keep it
+    c = ops.random_subset_select(E, keep, 9, dev, e_offset=0)
+    nested = ops.keep_mask(torch.stack([a, c]), E).cpu().numpy()
+    assert np.array_equal(nested, oracle.random_subset_mask(E, keep, 5) * oracle.random_subset_mask(E, keep, 9))
+    assert np.array_equal(nested, oracle.keep_mask(torch.stack([a, c]).cpu().numpy(), E))
 
 
 @pytest.mark.parametrize("F", [128, 64, 341, 4])

@@ -264,6 +264,30 @@ def test_edge_dropout_is_a_mask_view_with_the_same_product(selection):
     assert int(keep.sum()) == max(1, int(base.nnz * 0.75))
     ref = ops.CSRGraph(base._S.dst, base._S.src, nd, nd, vals=base._coo_vals * keep)
     assert torch.allclose(v2.spmm(x), ref.spmm(x), atol=1e-6) and torch.allclose(v2.spmm_t(x), ref.spmm_t(x), atol=1e-6)
+    # a dropout of the dropped view composes as the reference does (augmentation.py:113-124 on its own output): an
+    # exact max(1, int(E' * (1 - p))) of the E' survivors, all of them survivors of the first dropout
+    E1 = int(keep.sum())
+    v3 = G.random_edge_dropout_sparse(v2, 0.5, as_view=True, selection=selection)
+    keep3 = v3.survivors()
+    assert int(keep3.sum()) == max(1, int(E1 * 0.5)) and bool((keep3 <= keep).all())
+    ref3 = ops.CSRGraph(base._S.dst, base._S.src, nd, nd, vals=base._coo_vals * keep3)
+    assert torch.allclose(v3.spmm(x), ref3.spmm(x), atol=1e-6) and torch.allclose(v3.spmm_t(x), ref3.spmm_t(x), atol=1e-6)
+    v4 = G.random_edge_dropout_sparse_views([v2], 0.5)[0]
+    assert int(v4.survivors().sum()) == max(1, int(E1 * 0.5))
+    # ... and through sparse tensors: the second tensor's entries index the ROOT's CSR
+    d2 = G.random_edge_dropout_sparse(dropped, 0.5)
+    assert d2._values().shape[0] == max(1, int(dropped._values().shape[0] * 0.5))
+    view2 = L.adjacency_csr(d2)
+    assert view2.indptr is base.indptr and torch.allclose(view2.spmm(x), torch.spmm(d2, x), atol=1e-6)
+    # CSRGraph.dropped on a dropped view: the descriptions are ANDed (intersection), never silently ignored
+    if selection == "select":
+        d_a = ops.random_subset_select(base.nnz, base.nnz // 2, 11, CPU)
+        d_b = ops.random_subset_select(base.nnz, base.nnz // 2, 12, CPU)
+        both = base.dropped(d_a).dropped(d_b)
+        m = ops.keep_mask(d_a, base.nnz) * ops.keep_mask(d_b, base.nnz)
+        assert torch.equal(both.keep_mask(), m) and 0 < int(m.sum()) < base.nnz // 2
+        ref_ab = ops.CSRGraph(base._S.dst, base._S.src, nd, nd, vals=base._coo_vals * m)
+        assert torch.allclose(both.spmm(x), ref_ab.spmm(x), atol=1e-6)
 
 
 def test_random_subset_selection_is_exact_and_uniformish(oracle):
