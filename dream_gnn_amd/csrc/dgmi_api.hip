@@ -271,36 +271,6 @@ DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices,
   return from_hip(dgmi::spmm_sliced_f32(a, as_stream(stream)));
 }
 
-// Experimental (not yet in include/dgmi.h): row-owned slice-swept SpMM, see dgmi_swept.hip.  The caller builds the
-// layout for the geometry it passes (grid x waves x 64/lpr lane groups, R rows per group and round, Q rounds, S slices).
-DGMI_API size_t dgmi_x_spmm_swept_lds_bytes(int64_t F, int32_t waves, int32_t R, int32_t S, int32_t Q) {
-  return dgmi::swept_lds_bytes(F, waves, R, S * Q);
-}
-
-DGMI_API int dgmi_x_spmm_swept_f32(const int32_t* seg, const uint32_t* words, const float* vals, const float* X, int64_t ldx,
-                                   const float* src_scale, const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
-                                   int64_t n_src, int64_t F, int32_t S, int32_t Q, int32_t R, int32_t grid, int32_t waves,
-                                   int32_t lag, void* sync, size_t sync_bytes, int32_t act, float act_slope,
-                                   const float* out_mask, int64_t ld_mask, float out_mask_scale, dgmi_stream_t stream) {
-  if (n_dst < 0 || n_src < 0 || F < 0 || S < 1 || Q < 1 || R < 1 || R > 31 || grid < 1 || waves < 1 || waves > 16 ||
-      lag < -1 || !epilogue_ok(act, out_mask, ld_mask, F))
-    return DGMI_ERR_INVALID_ARG;
-  if (n_src >= (1 << 27) || n_dst >= INT32_MAX || (int64_t)S * Q > 4096) return DGMI_ERR_TOO_LARGE;
-  if (n_dst == 0 || F == 0) return DGMI_OK;
-  if (seg == nullptr || words == nullptr || X == nullptr || Y == nullptr || sync == nullptr) return DGMI_ERR_INVALID_ARG;
-  if (F > 256 || F % 4 != 0 || ldx < F || ldy < F || ldx % 4 != 0 || ldy % 4 != 0) return DGMI_ERR_INVALID_ARG;
-  if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(Y) & 15)) return DGMI_ERR_INVALID_ARG;
-  const int lpr = dgmi::swept_lpr(F);
-  const int64_t tg = (int64_t)grid * waves * (64 / lpr);
-  if (tg * R * Q < n_dst) return DGMI_ERR_INVALID_ARG;  // the geometry does not cover the rows
-  if (dgmi::swept_lds_bytes(F, waves, R, S * Q) > 160 * 1024) return DGMI_ERR_INVALID_ARG;
-  const int stride = (S * Q + 15) / 16 * 16;
-  if (sync_bytes < (size_t)8 * stride * sizeof(unsigned)) return DGMI_ERR_WORKSPACE;
-  dgmi::SweptArgs a{seg, words, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F, S, Q, R, grid, waves, lag,
-                    static_cast<unsigned*>(sync), stride, {act, act_slope, out_mask, ld_mask, out_mask_scale}};
-  return from_hip(dgmi::spmm_swept_f32(a, as_stream(stream)));
-}
-
 DGMI_API int dgmi_gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
                                     int64_t lda, int64_t Fa, const float* B, int64_t ldb, int64_t Fb,
                                     float* out, int64_t ldo, dgmi_stream_t stream) {

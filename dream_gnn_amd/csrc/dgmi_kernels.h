@@ -137,35 +137,6 @@ struct SlicedArgs {
 };
 hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s);
 
-// Row-owned, slice-swept SpMM (dgmi_swept.hip): lane groups own destination rows (sums in LDS) and sweep the
-// source slices phase by phase behind an advisory per-XCD-label barrier; no partial planes.
-struct SweptArgs {
-  const int32_t* seg;     // grid * waves * (64 / lpr) * S * Q + 1: first edge of every (group, phase)
-  const uint32_t* words;  // nnz: source id | local row << 27, grouped by (group, round, slice, local row)
-  const float* vals;      // nullable, layout order
-  const float* X;
-  int64_t ldx;
-  const float* src_scale;  // nullable
-  const float* dst_scale;  // nullable
-  float* Y;
-  int64_t ldy;
-  int64_t n_dst, n_src, F;
-  int S, Q, R;            // source slices, rounds over the destination rows, rows per group and round
-  int grid, waves;        // workgroups (all co-resident) x waves per workgroup
-  int lag;                // -1: no barrier; k >= 0: phase p starts when phase p - 1 - k is complete label-wide
-  unsigned* sync;         // 8 * sync_stride words of scratch (zeroed by the launcher)
-  int sync_stride;
-  Epilogue ep;
-};
-inline int swept_lpr(int64_t F) {
-  for (int lpr : {8, 16, 32}) {
-    if (4 * (int64_t)lpr >= F) return lpr;
-  }
-  return 64;
-}
-size_t swept_lds_bytes(int64_t F, int waves, int R, int PH);
-hipError_t spmm_swept_f32(const SweptArgs& a, hipStream_t s);
-
 // out[e] = cat(A[src[e]], B[dst[e]])   (dgmi_edge.hip)
 hipError_t gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
                              int64_t lda, int64_t Fa, const float* B, int64_t ldb, int64_t Fb,
