@@ -52,7 +52,18 @@ __device__ __forceinline__ void store_plane_row(float* p, const float4& v) {
 // bit of its source id; its gather repeats the group's previous row (an L1 hit — never one fixed row,
 // which would turn 10 % of all gathers into traffic on a single L2 channel) and its contribution is
 // replaced by zeros.
-template <int LPR, bool HAS_VALS, bool HAS_SS, bool KEEP>
+// Source row `idx` of the feature table.  OFF32: the table is < 4 GiB, so the byte offset fits 32 bits — one
+// v_mul_lo_u32 and a global_load with a scalar base and a 32-bit vector offset, instead of the six-instruction 64-bit
+// multiply-add chain a (int64 ldx) product costs per gathered row.
+template <bool OFF32>
+__device__ __forceinline__ float4 ld_row(const float* __restrict__ X, const float* __restrict__ Xc, int idx, int64_t ldx,
+                                         uint32_t row_bytes, uint32_t col_bytes) {
+  // X is the (wave-uniform) table base, Xc = X + this lane's column
+  if (OFF32) return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(X) + ((uint32_t)idx * row_bytes + col_bytes));
+  return ld4(Xc + (int64_t)idx * ldx);
+}
+
+template <int LPR, bool HAS_VALS, bool HAS_SS, bool KEEP, bool OFF32>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ indices,
     const float* __restrict__ vals, const float* __restrict__ X, int64_t ldx,
@@ -74,6 +85,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
   const bool col_ok = col < F;
   if (!col_ok) col = 0;
   const float* Xc = X + col;
+  const uint32_t row_bytes = (uint32_t)ldx * 4u, col_bytes = (uint32_t)col * 4u;
   const int32_t* sp = segptr + (int64_t)slice * n_dst + row0;
   float* prow = planes + ((int64_t)slice * (row_end - row_begin) + (row0 - row_begin)) * ldp + col;
 
@@ -121,7 +133,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
           idx = dropped && last_row >= 0 ? last_row : idx & 0x7fffffff;
           last_row = idx;
         }
-        v[u] = ld4(Xc + (int64_t)idx * ldx);
+        v[u] = ld_row<OFF32>(X, Xc, idx, ldx, row_bytes, col_bytes);
         if (dropped) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       // fast path (group-uniform): all 8 edges belong to the current row -> balanced tree, no
@@ -244,10 +256,19 @@ hipError_t launch_sliced(const SlicedArgs& a, int64_t row_begin, int64_t row_end
   dim3 grid((unsigned)(blocks * a.n_slices), (unsigned)((a.F + 4 * LPR - 1) / (4 * LPR)));
   dim3 block(kWave * kWavesPerBlock);
   const int key = (a.vals ? 4 : 0) | (a.src_scale ? 2 : 0) | (a.n_keep > 0 ? 1 : 0);
-#define DGMI_LAUNCH(V, S, K)                                                                          \
-  hipLaunchKernelGGL((spmm_sliced_vec4_kernel<LPR, V, S, K>), grid, block, 0, s, a.segptr, a.indices,  \
-                     a.vals, a.X, a.ldx, a.src_scale, a.planes, a.ldp, a.n_dst, row_begin, row_end,     \
-                     (int)a.F, (int)a.n_slices, a.eid, static_cast<const KeepSeg*>(a.keep), a.n_keep)
+  const bool no_off32 = getenv("DGMI_NO_OFF32") != nullptr;  // A/B switch (tools; read per call so one process can flip it)
+  const bool off32 = !no_off32 && (a.n_src * a.ldx + a.F) * 4 < ((int64_t)1 << 32);
+#define DGMI_LAUNCH(V, S, K)                                                                                    \
+  do {                                                                                                          \
+    if (off32)                                                                                                  \
+      hipLaunchKernelGGL((spmm_sliced_vec4_kernel<LPR, V, S, K, true>), grid, block, 0, s, a.segptr, a.indices,  \
+                         a.vals, a.X, a.ldx, a.src_scale, a.planes, a.ldp, a.n_dst, row_begin, row_end,          \
+                         (int)a.F, (int)a.n_slices, a.eid, static_cast<const KeepSeg*>(a.keep), a.n_keep);       \
+    else                                                                                                        \
+      hipLaunchKernelGGL((spmm_sliced_vec4_kernel<LPR, V, S, K, false>), grid, block, 0, s, a.segptr, a.indices, \
+                         a.vals, a.X, a.ldx, a.src_scale, a.planes, a.ldp, a.n_dst, row_begin, row_end,          \
+                         (int)a.F, (int)a.n_slices, a.eid, static_cast<const KeepSeg*>(a.keep), a.n_keep);       \
+  } while (0)
   switch (key) {
     case 0: DGMI_LAUNCH(false, false, false); break;
     case 1: DGMI_LAUNCH(false, false, true); break;
@@ -290,10 +311,8 @@ hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s) {
     // launch no longer fills the chip (config-5 edge-scaled shard, 6250 rows of 1600 edges: 0.382 -> 0.440 ms),
     // so the rule needs kColumnPassMinRows destination rows.
     // DGMI_SLICED_LPR forces a width (tools).
-    static const int forced_lpr = [] {
-      const char* e = getenv("DGMI_SLICED_LPR");
-      return e != nullptr ? atoi(e) : 0;
-    }();
+    const char* lpr_env = getenv("DGMI_SLICED_LPR");  // read per call: tools flip it inside one process
+    const int forced_lpr = lpr_env != nullptr ? atoi(lpr_env) : 0;
     int lpr = pick_lpr(a.F);
     if (lpr >= 32 && !a.full_width && a.n_keep == 0 && a.n_dst >= kColumnPassMinRows) {
       const int64_t width = 16 * (int64_t)lpr < 4 * a.F ? 16 * (int64_t)lpr : 4 * a.F;
