@@ -71,6 +71,65 @@ def _direct_exchange(out: torch.Tensor, y_local: torch.Tensor, bounds, rank: int
     return out
 
 
+XGMI_LINKS = 7            # point-to-point links per MI355X in a fully connected 8-GPU node
+XGMI_LINK_GBS = 153.0     # per link and direction (prompt / SURVEY §5: 7 x ~153 GB/s per GPU)
+
+
+def exchange_seconds(recv_bytes: float, world: int, form: str) -> float:
+    """The byte model DESIGN §6 states for one row-block exchange in which a rank receives ``recv_bytes``
+    in total: ``allgather`` is priced as RCCL's ring (every block crosses ONE link per step, world - 1 steps:
+    recv_bytes over one link), ``direct`` as world - 1 concurrent point-to-point transfers, one per link."""
+    if world <= 1 or recv_bytes <= 0:
+        return 0.0
+    links = 1 if form == "allgather" else min(world - 1, XGMI_LINKS)
+    return recv_bytes / (links * XGMI_LINK_GBS * 1e9)
+
+
+def predict_step_seconds(compute_s, recv_bytes, world: int, form: str) -> float:
+    """Step time of ``bench.py``'s schedule under that model: the products run back to back on the compute
+    stream; each product's exchange is queued on ONE side stream as soon as the product ends and runs behind
+    the exchanges queued before it; the step ends when both streams have drained."""
+    t_comp = t_comm = 0.0
+    for c, b in zip(compute_s, recv_bytes):
+        t_comp += c
+        t_comm = max(t_comm, t_comp) + exchange_seconds(b, world, form)
+    return max(t_comp, t_comm)
+
+
+def choose_exchange(time_fn, device, world: int, mode: str = "auto", group=None):
+    """Pick the row-block exchange form for this job.  ``time_fn(form) -> seconds per step`` runs a few steps
+    with that form (a collective: every rank calls it in the same order).  ``mode``: ``"allgather"`` /
+    ``"direct"`` force a form; ``"auto"`` times the all-gather (the well-trodden RCCL path) and then the
+    all-links form inside ``try`` — a form that raises on ANY rank is dropped on EVERY rank (the failure flag
+    is max-reduced before anything else happens), so an unsupported point-to-point path falls back to the
+    all-gather instead of killing the job.  Returns ``(form, report)``; ``report`` maps each form tried to its
+    max-over-ranks ms per step or to the error text."""
+    if world <= 1:
+        return None, None
+    if mode in ("allgather", "direct"):
+        return mode, None
+    if dist.get_backend(group) == "gloo":
+        device = "cpu"  # CPU rehearsals: the agreement travels as a host tensor
+    report, usable = {}, {}
+    for form in ("allgather", "direct"):
+        err, secs = None, 0.0
+        try:
+            secs = float(time_fn(form))
+        except Exception as exc:  # noqa: BLE001 - whatever the backend throws, the other form is still there
+            err = repr(exc)
+        flag = torch.tensor([1.0 if err is not None else 0.0, secs], dtype=torch.float64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if float(flag[0]) > 0:
+            report[form] = "failed: %s" % (err if err is not None else "on another rank")
+        else:
+            usable[form] = float(flag[1])
+            report[form] = round(float(flag[1]) * 1e3, 3)
+    if not usable:
+        raise RuntimeError("no row-block exchange form works on this job: %r" % (report,))
+    best = min(usable, key=usable.get)  # max-reduced timings: identical on every rank, so is the choice
+    return best, report
+
+
 def balanced_row_bounds(degree: torch.Tensor, parts: int) -> torch.Tensor:
     """Contiguous row ranges with ~equal nnz: int64[parts+1], bounds[0]=0, bounds[-1]=n_rows."""
     n = degree.shape[0]
@@ -121,10 +180,11 @@ class RowShard:
         ds = None if dst_scale is None else dst_scale.reshape(-1)[self.lo:self.hi].contiguous()
         return self.local.spmm(X, src_scale, ds, out=out)
 
-    #: how row blocks are exchanged: "allgather" (one RCCL all_gather_into_tensor; uneven blocks are
-    #: padded) or "direct" (batched point-to-point sends to every peer — all xGMI links at once, no
-    #: padding).  Same result; bench.py times both on the real node and uses the faster.
-    exchange = os.environ.get("DGMI_EXCHANGE", "allgather")
+    #: how row blocks are exchanged when the caller does not say: "allgather" (one RCCL
+    #: all_gather_into_tensor; uneven blocks are padded) or "direct" (batched point-to-point sends to every
+    #: peer — all xGMI links at once, no padding).  Same result.  DGMI_EXCHANGE=auto is resolved by the
+    #: job (``choose_exchange``: bench.py times both on the real node, guarded, and passes the winner in).
+    exchange = {"direct": "direct"}.get(os.environ.get("DGMI_EXCHANGE", ""), "allgather")
 
     def gather_rows(self, y_local: torch.Tensor, group=None, out: Optional[torch.Tensor] = None,
                     exchange: Optional[str] = None):

@@ -140,6 +140,84 @@ def test_direct_exchange_indexing_world4():
     assert all(ok for _, ok in res), res
 
 
+def _auto_worker(rank, world, port, q, break_direct):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+
+        import _cpu_backend
+        from dream_gnn_amd import shard
+
+        dst, src, val, X, dY, ss, ds, n_dst, n_src = _graph(True)
+        t = torch.from_numpy
+        if break_direct:  # what an unsupported point-to-point path looks like: the call raises
+            def broken(*a, **k):
+                raise RuntimeError("batch_isend_irecv: not supported on this transport")
+            shard._direct_exchange = broken
+        with _cpu_backend.patched():
+            deg = torch.bincount(t(dst), minlength=n_dst)
+            sh = shard.RowShard(t(dst), t(src), n_dst, n_src, shard.balanced_row_bounds(deg, world), rank, vals=t(val))
+            y_local = sh.spmm_local(t(X), t(ss), t(ds))
+
+            def time_fn(form):
+                t0 = time.perf_counter()
+                sh.gather_rows(y_local, exchange=form)
+                return time.perf_counter() - t0
+
+            form, report = shard.choose_exchange(time_fn, "cpu", world, mode="auto")
+            y = sh.gather_rows(y_local, exchange=form)
+            forced, none = shard.choose_exchange(time_fn, "cpu", world, mode="allgather")
+        q.put((rank, form, report, y.numpy().copy(), forced, none))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("break_direct", [True, False])
+def test_exchange_auto_falls_back_when_the_all_links_form_raises(oracle, break_direct):
+    """bench.py's default (DGMI_EXCHANGE=auto -> shard.choose_exchange): both forms are tried, a form that raises is
+    dropped on EVERY rank (no rank is left inside a collective), all ranks agree on the survivor, and the result
+    assembled with it is the full product."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_auto_worker, args=(r, 2, port, q, break_direct)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    dst, src, val, X, dY, ss, ds, n_dst, n_src = _graph(True)
+    ip, ix, eid = oracle.csr_from_coo(dst, src, n_dst)
+    ref = oracle.spmm_csr(ip, ix, val[eid], X, ss, ds, acc="f64")
+    forms = {r[1] for r in res}
+    assert len(forms) == 1 and forms <= {"allgather", "direct"}
+    for _, form, report, y, forced, none in res:
+        assert set(report) == {"allgather", "direct"} and forced == "allgather" and none is None
+        assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
+        if break_direct:
+            assert form == "allgather" and str(report["direct"]).startswith("failed") and isinstance(report["allgather"], float)
+        else:
+            assert isinstance(report["direct"], float)
+
+
+def test_exchange_byte_model():
+    """DESIGN 6's prediction model as bench.py applies it (host arithmetic)."""
+    from dream_gnn_amd import shard as S
+
+    assert S.exchange_seconds(153e9, 8, "allgather") == pytest.approx(1.0) and S.exchange_seconds(153e9, 8, "direct") == pytest.approx(1 / 7)
+    assert S.exchange_seconds(153e9, 2, "direct") == pytest.approx(1.0) and S.exchange_seconds(1e9, 1, "direct") == 0.0
+    # two products of 1 s each; the first exchange (0.5 s) hides behind the second product, the last one is exposed
+    assert S.predict_step_seconds([1.0, 1.0], [0.5 * 153e9, 0.25 * 153e9], 8, "allgather") == pytest.approx(2.25)
+    # an exchange longer than the next product queues the following one behind it
+    assert S.predict_step_seconds([1.0, 1.0], [2 * 153e9, 153e9], 8, "allgather") == pytest.approx(4.0)
+    assert S.predict_step_seconds([1.0, 1.0], [0.0, 0.0], 1, "direct") == pytest.approx(2.0)
+
+
 def test_balanced_row_bounds_properties():
     from dream_gnn_amd.shard import balanced_row_bounds, choose_row_bounds
 
