@@ -303,6 +303,24 @@ DGMI_API int dgmi_epilogue_backward_f32(const float* dY, const float* Y, const f
   return from_hip(dgmi::epilogue_backward_f32(dY, Y, mask, n, act, act_slope, mask_scale, out, as_stream(stream)));
 }
 
+DGMI_API int dgmi_weighted_colsum_f32(const float* A, int64_t lda, const float* coef, int64_t ldc, int64_t n, int64_t W,
+                                      int32_t B, float* out, int64_t ldo, dgmi_stream_t stream) {
+  if (n < 0 || W < 0 || B < 0 || B > 64 || lda < W || ldo < W || ldc < n) return DGMI_ERR_INVALID_ARG;
+  if (W > INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (W == 0 || B == 0) return DGMI_OK;
+  if (out == nullptr || coef == nullptr || (A == nullptr && n > 0)) return DGMI_ERR_INVALID_ARG;
+  return from_hip(dgmi::weighted_colsum_f32(A, lda, coef, ldc, n, W, B, out, ldo, as_stream(stream)));
+}
+
+DGMI_API int dgmi_rank_add_f32(float* G, int64_t ldg, const float* coef, int64_t ldc, const float* gs, int64_t lds, int64_t n,
+                               int64_t W, int32_t B, dgmi_stream_t stream) {
+  if (n < 0 || W < 0 || B < 0 || B > 64 || ldg < W || lds < W || ldc < n) return DGMI_ERR_INVALID_ARG;
+  if (W > INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (n == 0 || W == 0 || B == 0) return DGMI_OK;
+  if (G == nullptr || coef == nullptr || gs == nullptr) return DGMI_ERR_INVALID_ARG;
+  return from_hip(dgmi::rank_add_f32(G, ldg, coef, ldc, gs, lds, n, W, B, as_stream(stream)));
+}
+
 DGMI_API size_t dgmi_random_subset_workspace_bytes(void) { return dgmi::random_subset_workspace_bytes(); }
 
 DGMI_API int dgmi_random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask, void* workspace,

@@ -201,4 +201,78 @@ hipError_t epilogue_backward_f32(const float* dY, const float* Y, const float* m
   return hipGetLastError();
 }
 
+// (f3, complement form) out[b, c] = sum_u coef[b, u] * A[u * lda + c] — the column sums of the scaled transformed
+// features of the near-complete relation, one per block (graph.py fused_relations_complement).  A library
+// GEMM with M = 1..8 takes 34 us for this on MI355X; it is a 1 MB streaming read.  One workgroup per 64 columns and
+// block, lanes across the columns (coalesced 256-B reads), fixed summation order -> bitwise reproducible.
+namespace {
+constexpr int kColsumWaves = 16;
+__global__ __launch_bounds__(64 * kColsumWaves) void weighted_colsum_kernel(const float* __restrict__ A, int64_t lda,
+                                                                            const float* __restrict__ coef, int64_t ldc,
+                                                                            int64_t n, int W, float* __restrict__ out,
+                                                                            int64_t ldo) {
+  // 16 waves per workgroup, wave w takes rows w, w + 16, ...; 8 independent row loads in flight per lane (the sum is
+  // latency-bound: 6 workgroups read 1 MB), partial sums added in a fixed order: per lane over its rows, then the 8
+  // accumulators, then the 16 waves through LDS
+  __shared__ float part[kColsumWaves][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = (int)blockIdx.x * 64 + lane;
+  const float* cf = coef + (int64_t)blockIdx.y * ldc;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < W) {
+    int64_t u = wave;
+    for (; u + 7 * kColsumWaves < n; u += 8 * kColsumWaves) {
+      float v[8], w[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[k] = A[(u + k * kColsumWaves) * lda + c];
+        w[k] = cf[u + k * kColsumWaves];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = fmaf(w[k], v[k], acc[k]);
+    }
+    for (int k = 0; u < n; u += kColsumWaves, ++k) acc[k] = fmaf(cf[u], A[u * lda + c], acc[k]);
+  }
+  part[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (wave == 0 && c < W) {
+    float t = part[0][lane];
+#pragma unroll
+    for (int k = 1; k < kColsumWaves; ++k) t += part[k][lane];
+    out[(int64_t)blockIdx.y * ldo + c] = t;
+  }
+}
+
+// G[u * ldg + c] += sum_b coef[b, u] * gs[b * lds + c]: the column sums' gradient handed back to every source row
+__global__ __launch_bounds__(256) void rank_add_kernel(float* __restrict__ G, int64_t ldg, const float* __restrict__ coef,
+                                                       int64_t ldc, const float* __restrict__ gs, int64_t lds, int64_t n,
+                                                       int W, int B) {
+  const int64_t total = n * W, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int64_t u = i / W;
+    const int c = (int)(i - u * W);
+    float add = 0.f;
+    for (int b = 0; b < B; ++b) add = fmaf(coef[(int64_t)b * ldc + u], gs[(int64_t)b * lds + c], add);
+    G[u * ldg + c] += add;
+  }
+}
+}  // namespace
+
+hipError_t weighted_colsum_f32(const float* A, int64_t lda, const float* coef, int64_t ldc, int64_t n, int64_t W, int B,
+                               float* out, int64_t ldo, hipStream_t s) {
+  if (W == 0 || B == 0) return hipSuccess;
+  hipLaunchKernelGGL(weighted_colsum_kernel, dim3((unsigned)((W + 63) / 64), (unsigned)B), dim3(64 * kColsumWaves), 0, s, A, lda, coef, ldc,
+                     n, (int)W, out, ldo);
+  return hipGetLastError();
+}
+
+hipError_t rank_add_f32(float* G, int64_t ldg, const float* coef, int64_t ldc, const float* gs, int64_t lds, int64_t n,
+                        int64_t W, int B, hipStream_t s) {
+  if (n == 0 || W == 0 || B == 0) return hipSuccess;
+  int64_t blocks = (n * W + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(rank_add_kernel, dim3((unsigned)blocks), dim3(256), 0, s, G, ldg, coef, ldc, gs, lds, n, (int)W, B);
+  return hipGetLastError();
+}
+
 }  // namespace dgmi

@@ -23,11 +23,14 @@ struct KeepSeg {
   uint32_t seed_lo, seed_hi;
   uint32_t thr;
   int32_t tie_cut;  // local edge id; -1: no tie kept
-  uint32_t reserved0, reserved1;
+  uint32_t flags;   // bit 0 (kKeepInvert): the segment keeps exactly the edges the description DROPS — the complement
+                    // form of a near-complete relation subtracts its dropped edges (graph.py fused_relations_complement)
+  uint32_t reserved1;
 };
 static_assert(sizeof(KeepSeg) == 32, "KeepSeg is 8 words in the C ABI");
 
 constexpr int kMaxKeepSegs = 8;
+constexpr uint32_t kKeepInvert = 1u;
 constexpr uint32_t kDroppedBit = 0x80000000u;  // flag carried in the sign bit of a source id
 
 __device__ __forceinline__ uint32_t edge_hash(uint64_t seed, uint64_t e) {
@@ -47,7 +50,8 @@ __device__ __forceinline__ bool edge_kept(const KeepSeg* __restrict__ tab, int n
     if (e >= sg.e_begin && e < sg.e_end) {
       const uint32_t local = e - sg.e_begin;
       const uint32_t h = edge_hash(((uint64_t)sg.seed_hi << 32) | sg.seed_lo, local);
-      if (!(h < sg.thr || (h == sg.thr && (int32_t)local <= sg.tie_cut))) return false;
+      const bool in_subset = h < sg.thr || (h == sg.thr && (int32_t)local <= sg.tie_cut);
+      if (in_subset == ((sg.flags & kKeepInvert) != 0u)) return false;
     }
   }
   return true;

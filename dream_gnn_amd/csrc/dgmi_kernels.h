@@ -151,6 +151,12 @@ hipError_t gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, con
 hipError_t epilogue_backward_f32(const float* dY, const float* Y, const float* mask, int64_t n, int act, float slope,
                                  float mask_scale, float* out, hipStream_t s);
 
+// (f3 complement form) weighted column sums of a strided row set, and their gradient added back (dgmi_edge.hip)
+hipError_t weighted_colsum_f32(const float* A, int64_t lda, const float* coef, int64_t ldc, int64_t n, int64_t W, int B,
+                               float* out, int64_t ldo, hipStream_t s);
+hipError_t rank_add_f32(float* G, int64_t ldg, const float* coef, int64_t ldc, const float* gs, int64_t lds, int64_t n,
+                        int64_t W, int B, hipStream_t s);
+
 // mask[e] = 1 for a uniformly random subset of exactly `keep` of the E edges (dgmi_select.hip)
 size_t random_subset_workspace_bytes();
 // the 8-word description (dgmi_keep.h) of a uniformly random subset of exactly `keep` of E edges

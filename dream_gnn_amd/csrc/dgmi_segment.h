@@ -110,6 +110,27 @@ __device__ __forceinline__ void gather_batch(const float* __restrict__ Xc, int64
   }
 }
 
+// Edge dropout on the fly, wave-per-segment kernels: the ids of one 64-lane batch come with the dropped ones flagged
+// in the sign bit.  The survivors are moved, in order, to lanes [0, cnt) with ONE ds_permute per register (a full
+// permutation: survivor -> its rank, dropped lane -> cnt + its rank among the dropped), so the gather loop only ever
+// sees live edges: a dropped edge costs its id fetch and one hash, not a load slot — which is what makes segments
+// that drop MOST of their edges (the inverted segment of the complement form, dgmi_keep.h) cheap — and the kept
+// edges are summed in exactly the order a CSR rebuilt from them would give (the reference's construction).
+// Returns cnt; ids come back unflagged (every lane holds a valid row id).
+__device__ __forceinline__ int compact_live(int& idx, float& w, bool weighted, int n, int lane) {
+  const bool live = lane < n && idx >= 0;
+  const unsigned long long m = __ballot(live);
+  const int cnt = __popcll(m);
+  if (cnt < n) {
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    const int target = (live ? rank : cnt + (lane - rank)) << 2;
+    idx = __builtin_amdgcn_ds_permute(target, idx);
+    if (weighted) w = __int_as_float(__builtin_amdgcn_ds_permute(target, __float_as_int(w)));
+  }
+  idx &= 0x7fffffff;
+  return cnt;
+}
+
 // Sum of edges [start, end) of one row over this lane's 4 columns; the result
 // is complete (all 64/LPR lane groups combined) in every lane.
 // id of edge q as the gathers will use it: the source id, with (KEEP) kDroppedBit set when
@@ -148,9 +169,9 @@ __device__ __forceinline__ float4 segment_vec4(const int32_t* __restrict__ indic
     }
   }
   for (int base = start; base < end; base += kWave) {
-    const int my_idx = nxt_idx;
-    const float my_w = nxt_w;
-    const int n = end - base;
+    int my_idx = nxt_idx;
+    float my_w = nxt_w;
+    int n = end - base;
     const int nb = base + kWave;
     if (nb < end) {
       const int p = nb + lane;
@@ -162,10 +183,14 @@ __device__ __forceinline__ float4 segment_vec4(const int32_t* __restrict__ indic
         nxt_w = w;
       }
     }
+    if (KEEP) {
+      n = compact_live(my_idx, my_w, WEIGHTED, n < kWave ? n : kWave, lane);
+      if (n == 0) continue;  // wave-uniform
+    }
     if (n >= kWave)
-      gather_batch<LPR, WEIGHTED, true, KEEP>(Xc, ldx, my_idx, my_w, kWave, sub, acc);
+      gather_batch<LPR, WEIGHTED, true, false>(Xc, ldx, my_idx, my_w, kWave, sub, acc);
     else
-      gather_batch<LPR, WEIGHTED, false, KEEP>(Xc, ldx, my_idx, my_w, n, sub, acc);
+      gather_batch<LPR, WEIGHTED, false, false>(Xc, ldx, my_idx, my_w, n, sub, acc);
   }
   // combine the 64/LPR partial rows (fixed order -> deterministic)
 #pragma unroll
@@ -190,30 +215,25 @@ __device__ __forceinline__ float segment_dword(const int32_t* __restrict__ indic
   constexpr bool WEIGHTED = HAS_VALS || HAS_SS;
   float acc = 0.f;
   for (int base = start; base < end; base += kWave) {
-    const int n = min(kWave, end - base);
+    int n = min(kWave, end - base);
     const int q = lane < n ? base + lane : base;
-    const int my_idx = fetch_id<KEEP>(indices, eid, keep, n_keep, q);
+    int my_idx = fetch_id<KEEP>(indices, eid, keep, n_keep, q);
     float my_w = 0.f;
     if (WEIGHTED) {
       my_w = HAS_VALS ? vals[q] : 1.f;
       if (HAS_SS) my_w *= src_scale[KEEP ? my_idx & 0x7fffffff : my_idx];
     }
+    if (KEEP) n = compact_live(my_idx, my_w, WEIGHTED, n, lane);  // survivors in lanes [0, n), every lane a valid id
 #pragma unroll 1
     for (int s = 0; s < n; s += kUnroll) {
       float v[kUnroll], w[kUnroll];
-      int last = -1;
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
         const int e = s + u;  // < 64 because n <= 64 and 64 % kUnroll == 0
-        int idx = __shfl(my_idx, e, kWave);
+        const int idx = __shfl(my_idx, e, kWave);
         if (WEIGHTED) w[u] = __shfl(my_w, e, kWave);
-        const bool dropped = KEEP && idx < 0;
-        if (KEEP) {
-          idx = dropped && last >= 0 ? last : idx & 0x7fffffff;
-          last = idx;
-        }
         v[u] = Xc[(int64_t)idx * ldx];
-        if (e >= n || dropped) v[u] = 0.f;
+        if (e >= n) v[u] = 0.f;
       }
       if (WEIGHTED) {
 #pragma unroll

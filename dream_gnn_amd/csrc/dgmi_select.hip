@@ -69,7 +69,7 @@ __device__ __forceinline__ void write_desc(KeepSeg* out, int64_t E, uint64_t see
   sg.seed_hi = (uint32_t)(seed >> 32);
   sg.thr = thr;
   sg.tie_cut = tie_cut;
-  sg.reserved0 = sg.reserved1 = 0;
+  sg.flags = sg.reserved1 = 0;
   *out = sg;
 }
 

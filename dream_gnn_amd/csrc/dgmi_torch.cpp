@@ -361,6 +361,32 @@ Tensor epilogue_backward(const Tensor& dY, const Tensor& Y, const OptTensor& mas
   return out;
 }
 
+// (f3 complement form) rows [n*R, n*R + B) of `feat_ext` <- coef @ feat_ext[u*R + i0, :] (column sums per block), in place
+void colsum_rows_(Tensor feat_ext, const Tensor& coef, int64_t n, int64_t R, int64_t i0) {
+  check(feat_ext, at::kFloat, 2, "feat_ext", feat_ext);
+  check(coef, at::kFloat, 2, "coef", feat_ext);
+  const int64_t B = coef.size(0), W = feat_ext.size(1);
+  TORCH_CHECK(coef.size(1) == n && feat_ext.size(0) == n * R + B && i0 >= 0 && i0 < R && B <= 64,
+              "colsum_rows_: feat_ext must have n*R + B rows, coef (B, n)");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(feat_ext.device());
+  float* base = feat_ext.data_ptr<float>();
+  check_status(dgmi_weighted_colsum_f32(base + i0 * W, R * W, coef.data_ptr<float>(), n, n, W, (int32_t)B, base + n * R * W, W,
+                                        stream_of(feat_ext)), "dgmi_weighted_colsum_f32");
+}
+
+// its backward: gf[u*R + i0, :] += coef[:, u]^T @ gs, in place on the (n*R, W) gradient of the transform
+void colsum_rows_backward_(Tensor gf, const Tensor& coef, const Tensor& gs, int64_t n, int64_t R, int64_t i0) {
+  check(gf, at::kFloat, 2, "gf", gf);
+  check(coef, at::kFloat, 2, "coef", gf);
+  check(gs, at::kFloat, 2, "gs", gf);
+  const int64_t B = coef.size(0), W = gf.size(1);
+  TORCH_CHECK(coef.size(1) == n && gf.size(0) == n * R && gs.size(0) == B && gs.size(1) == W && i0 >= 0 && i0 < R && B <= 64,
+              "colsum_rows_backward_: shape mismatch");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(gf.device());
+  check_status(dgmi_rank_add_f32(gf.data_ptr<float>() + i0 * W, R * W, coef.data_ptr<float>(), n, gs.data_ptr<float>(), W, n, W,
+                                 (int32_t)B, stream_of(gf)), "dgmi_rank_add_f32");
+}
+
 // (f4) (N, k) int32 neighbours of the k largest cosine similarities per row of a row-normalised matrix
 Tensor knn_cosine_topk(const Tensor& Xn, int64_t k) {
   Dense x = dense_of(Xn, "Xn");
@@ -520,6 +546,8 @@ TORCH_LIBRARY(dreamgnn_mi, m) {
         "float mask_scale=1., int column_passes=0) -> ()");
   m.def("epilogue_backward(Tensor dY, Tensor Y, Tensor? mask, int act, float slope, float mask_scale) -> Tensor");
   m.def("knn_cosine_topk(Tensor Xn, int k) -> Tensor");
+  m.def("colsum_rows_(Tensor(a!) feat_ext, Tensor coef, int n, int R, int i0) -> ()");
+  m.def("colsum_rows_backward_(Tensor(a!) gf, Tensor coef, Tensor gs, int n, int R, int i0) -> ()");
   m.def("gather_f32(Tensor values, Tensor perm) -> Tensor");
   m.def("gather_concat_raw(Tensor src, Tensor dst, Tensor A, Tensor B) -> Tensor");
   m.def("gather_add_raw(Tensor src, Tensor dst, Tensor A, Tensor B, Tensor? bias) -> Tensor");
@@ -541,6 +569,8 @@ TORCH_LIBRARY_IMPL(dreamgnn_mi, CUDA, m) {
   m.impl("spmm_sliced_out", spmm_sliced_out);
   m.impl("epilogue_backward", epilogue_backward);
   m.impl("knn_cosine_topk", knn_cosine_topk);
+  m.impl("colsum_rows_", colsum_rows_);
+  m.impl("colsum_rows_backward_", colsum_rows_backward_);
   m.impl("gather_f32", gather_f32);
   m.impl("gather_concat_raw", gather_concat_raw);
   m.impl("gather_add_raw", gather_add_raw);

@@ -10,11 +10,17 @@ COO tensors and lazily built device CSRs (``ops.CSRGraph``).  Nothing here depen
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
 
 from . import ops
+
+# (f3) complement form of a near-complete relation (HeteroGraph.fused_relations_complement): taken from this
+# share of the cells up (a value > 1 switches it off); the dense presence map it is built from stays small
+COMPLEMENT_MIN_DENSITY = float(os.environ.get("DGMI_COMPLEMENT_MIN_DENSITY", "0.5"))
+COMPLEMENT_MAX_CELLS = 1 << 26
 
 CanonicalEType = Tuple[str, str, str]
 
@@ -347,6 +353,109 @@ class HeteroGraph:
         cache[dst_type] = out
         return out
 
+    def fused_relations_complement(self, dst_type: str):
+        """The fused relations of :meth:`fused_relations` in COMPLEMENT form (f3), or ``None``.
+
+        The reference's encoder graph holds EVERY train pair, both labels (data_loader.py:146-150,170), so
+        the label-0 relation of a real dataset is a near-complete bipartite block (lrssl shape: 464 897 of
+        519 603 cells) and ``A_0 H = 1 colsum(H)^T - C H`` with ``C`` = the cells NOT in ``A_0`` (the other
+        label's pairs and the held-out test pairs: ~55 k) gathers 8x fewer rows.  A block-diagonal union of
+        datasets (BASELINE config 3, "Cdataset + Gdataset merged") is near-complete per BLOCK: the identity then
+        holds block by block, with one column sum per block (blocks = connected components of relation i0, at most 8).
+        Returned ``(csr, cans, i0, blockmat)``: ``csr`` has the fused layout's columns ``R*u + r`` plus one virtual
+        source ``R*n_src + b`` per block whose feature row the caller sets to
+        ``blockmat[b] @ (scale_i0 * feat_i0)`` (``blockmat``: (B, n_src) 0/1), and signed unit values:
+
+            relation r != i0     its edges,            value +1   (a dropped child: its description)
+            complement cells C   (v, R*u + i0),        value -1
+            dropped child only   relation i0's edges,  value -1   under its description INVERTED (dgmi_keep.h
+                                 kKeepInvert): A_0^kept H = 1 colsum^T - C H - A_0^dropped H — the kernels move
+                                 the ~10 % that take part to the front of each id batch, the other 90 % cost
+                                 one hash each and no load
+            every destination    (v, R*n_src + block(v)),  value +1
+
+        so ``diag(ci) csr diag(scale_ext) feat_ext`` is the hetero-sum aggregate exactly (up to fp32
+        summation order).  Taken when relation i0 covers at least ``COMPLEMENT_MIN_DENSITY`` of the cells
+        and has no repeated cell (``A_0`` must be 0/1 for the identity to hold; one readback at build)."""
+        cache = self.__dict__.setdefault("_fused_complement", {})
+        if dst_type in cache:
+            return cache[dst_type]
+        out = None
+        parent = self.__dict__.get("_dropout_parent")
+        fr = self.fused_relations(dst_type)
+        if fr is not None and parent is not None and all(isinstance(self._rels[c], DroppedRelation) for c in fr[1]):
+            struct = parent._complement_struct(dst_type, with_dense_relation=True)
+            if struct is not None:
+                csr, cans, i0, blockmat, starts = struct
+                rels = [self._rels[c] for c in cans]
+                if all(r.desc is not None for r in rels) and len(rels) <= 8:
+                    key = ("_complement_offsets", dst_type)
+                    offs = parent.__dict__.get(key)
+                    if offs is None:
+                        offs = torch.zeros((len(cans), 8), dtype=torch.int32)
+                        offs[:, 0] = offs[:, 1] = torch.tensor(starts, dtype=torch.int32)
+                        offs[i0, 6] = 1  # kKeepInvert: relation i0's DROPPED edges are the ones subtracted
+                        offs = parent.__dict__[key] = offs.to(rels[0].desc.device)
+                    view = csr.dropped(torch.stack([r.desc for r in rels]) + offs)
+                else:  # 0/1 masks (the reference's literal randperm selection)
+                    parts = [(1.0 - r.keep_mask()) if i == i0 else r.keep_mask() for i, r in enumerate(rels)]
+                    tail = torch.ones(csr.nnz - sum(int(p.numel()) for p in parts), dtype=torch.float32, device=csr.device)
+                    view = csr.masked(torch.cat(parts + [tail]))
+                out = (view, cans, i0, blockmat)
+        elif fr is not None and parent is None and not any(isinstance(r, DroppedRelation) for r in self._rels.values()):
+            struct = self._complement_struct(dst_type, with_dense_relation=False)
+            if struct is not None:
+                out = struct[:4]
+        cache[dst_type] = out
+        return out
+
+    def _complement_struct(self, dst_type: str, with_dense_relation: bool):
+        """``(csr, cans, i0, blockmat, starts)`` of the complement form on THIS (un-dropped) graph; ``with_dense_relation``:
+        also carry relation i0's own edges (value -1) for dropped children to subtract their dropped part."""
+        cache = self.__dict__.setdefault("_complement_structs", {})
+        key = (dst_type, with_dense_relation)
+        if key in cache:
+            return cache[key]
+        out = None
+        fr = self.fused_relations(dst_type)
+        if fr is not None and COMPLEMENT_MIN_DENSITY <= 1.0:
+            cans = fr[1]
+            rels = [self._rels[c] for c in cans]
+            R, n_src, n_dst = len(cans), rels[0].n_src, rels[0].n_dst
+            cells = n_src * n_dst
+            i0 = max(range(R), key=lambda i: rels[i].number_of_edges())
+            E0 = rels[i0].number_of_edges()
+            if 0 < cells <= COMPLEMENT_MAX_CELLS and E0 >= COMPLEMENT_MIN_DENSITY * 0.25 * cells and R * n_src + 8 < 2 ** 31 - 1:
+                dev = rels[i0].src.device
+                present = torch.zeros((n_dst, n_src), dtype=torch.bool, device=dev)
+                present[rels[i0].dst.long(), rels[i0].src.long()] = True
+                blocks = _bipartite_blocks(present) if int(present.sum()) == E0 else None  # repeated cell: A_i0 is not 0/1
+                if blocks is not None:
+                    blk_dst, blk_src, B = blocks  # block id per node (-1: no cell of relation i0), B <= 8 blocks
+                    support = (blk_dst.view(-1, 1) == blk_src.view(1, -1)) & (blk_dst.view(-1, 1) >= 0)
+                    if E0 >= COMPLEMENT_MIN_DENSITY * int(support.sum()):
+                        cv, cu = torch.nonzero(support & ~present, as_tuple=True)  # complement cells, row-major
+                        dst_parts, col_parts, val_parts, starts, acc = [], [], [], [], 0
+                        for i, r in enumerate(rels):
+                            starts.append(acc)
+                            if i == i0 and not with_dense_relation:
+                                continue
+                            dst_parts.append(r.dst.to(torch.int32))
+                            col_parts.append(r.src.to(torch.int32) * R + i)
+                            val_parts.append(torch.full((r.number_of_edges(),), -1.0 if i == i0 else 1.0, device=dev))
+                            acc += r.number_of_edges()
+                        has = torch.nonzero(blk_dst >= 0, as_tuple=True)[0]  # destinations with a block: one edge to its column sum
+                        dst_parts += [cv.to(torch.int32), has.to(torch.int32)]
+                        col_parts += [(cu * R + i0).to(torch.int32), (R * n_src + blk_dst[has]).to(torch.int32)]
+                        val_parts += [torch.full((cv.numel(),), -1.0, device=dev), torch.ones(has.numel(), device=dev)]
+                        csr = ops.CSRGraph(torch.cat(dst_parts), torch.cat(col_parts), n_dst, R * n_src + B,
+                                           vals=torch.cat(val_parts), check_range=not all(r.trusted for r in rels))
+                        # (B, n_src) 0/1: block b's column sum is blockmat[b] @ (scale_i0 * feat_i0)
+                        blockmat = (blk_src.view(1, -1) == torch.arange(B, device=dev).view(-1, 1)).to(torch.float32)
+                        out = (csr, cans, i0, blockmat, starts)
+        cache[key] = out
+        return out
+
     def edge_pairs(self, etype=None) -> "ops.EdgePairs":
         """Kernel-side view of one relation's edge list for the decoder gather-concat."""
         rel = self[etype] if etype is not None else self._single()
@@ -437,6 +546,33 @@ def from_dgl(g) -> HeteroGraph:
         for key, val in g.nodes[nt].data.items():
             out.nodes[nt].data[key] = val
     return out
+
+
+def _bipartite_blocks(present: torch.Tensor, max_blocks: int = 8):
+    """Connected components of the bipartite graph whose cells are ``present`` (n_dst, n_src bool):
+    ``(block_of_dst, block_of_src, B)`` with ids 0..B-1 (-1 for nodes without a cell), or ``None`` when there are
+    more than ``max_blocks`` components.  Min-label propagation over the dense map: a near-complete block
+    converges in two sweeps; a few host readbacks, at graph build only."""
+    n_dst, n_src = present.shape
+    big = n_src + n_dst
+    lab_src = torch.arange(n_src, device=present.device, dtype=torch.int32)
+    lab_dst = torch.full((n_dst,), big, device=present.device, dtype=torch.int32)
+    fill = torch.full((1, 1), big, dtype=torch.int32, device=present.device)
+    for _ in range(64):
+        new_dst = torch.where(present, lab_src.view(1, -1), fill).min(dim=1).values
+        new_src = torch.minimum(lab_src, torch.where(present, new_dst.view(-1, 1), fill).min(dim=0).values)
+        done = bool(torch.equal(new_src, lab_src) and torch.equal(new_dst, lab_dst))
+        lab_src, lab_dst = new_src, new_dst
+        if done:
+            break
+    has_src = present.any(dim=0)
+    roots = torch.unique(lab_src[has_src])
+    if roots.numel() == 0 or roots.numel() > max_blocks:
+        return None
+    blk_src = torch.where(has_src, torch.searchsorted(roots, lab_src), torch.full_like(lab_src, -1))
+    has_dst = lab_dst < big
+    blk_dst = torch.where(has_dst, torch.searchsorted(roots, lab_dst.clamp(max=int(roots.max()))), torch.full_like(lab_dst, -1))
+    return blk_dst.to(torch.int64), blk_src.to(torch.int64), int(roots.numel())
 
 
 def _draw_seed(generator: Optional[torch.Generator]) -> Optional[int]:

@@ -197,6 +197,38 @@ def _as_hetero(graph):
     return hit
 
 
+class _ExtendedFeat(torch.autograd.Function):
+    """Rows ``[u][r]`` of ``x @ [W_0 | ... | W_{R-1}]`` followed by ``B`` rows ``coef @ feat[:, i0, :]`` (the column sums
+    the complement form needs, one per block; ``coef`` = block indicator x ``dropout(cj)`` of relation i0, (B, n)),
+    produced in ONE buffer: ``(n*R + B, W)``.  Two GEMMs forward, no concatenation pass; the backward folds the
+    column sums' gradient back into relation i0's rows before the two GEMMs of the transform's own backward."""
+
+    @staticmethod
+    def build(x, w_cat, coef, R, i0):
+        n, rw = x.shape[0], w_cat.shape[1]
+        buf = x.new_empty((n * R + coef.shape[0], rw // R))
+        torch.mm(x, w_cat, out=buf[: n * R].view(n, rw))
+        return ops.colsum_rows_(buf, coef, n, R, i0)
+
+    @staticmethod
+    def forward(ctx, x, w_cat, coef, R, i0):
+        buf = _ExtendedFeat.build(x, w_cat, coef, R, i0)
+        ctx.save_for_backward(x, w_cat, coef)
+        ctx.dims = (x.shape[0], R, w_cat.shape[1] // R, coef.shape[0], i0)
+        return buf
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w_cat, coef = ctx.saved_tensors
+        n, R, W, B, i0 = ctx.dims
+        gf = g[: n * R].clone()
+        ops.colsum_rows_backward_(gf, coef, g[n * R:].contiguous(), n, R, i0)  # every source of a block receives its column sum's gradient
+        gf = gf.view(n, R * W)
+        dx = torch.mm(gf, w_cat.t()) if ctx.needs_input_grad[0] else None
+        dw = torch.mm(x.t(), gf) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None, None
+
+
 class GCMCLayer(nn.Module):
     """layers.py:18-143.  Parameters: ``att`` (R,B), ``basis`` (B,in,msg), ``ufc`` (and ``ifc``,
     the same module when sharing), plus ``conv.mods.<etype>.weight`` in the unshared branch."""
@@ -278,6 +310,11 @@ class GCMCLayer(nn.Module):
         drug = self.dropout(self.agg_act(out["drug"]))
         dis = self.dropout(self.agg_act(out["disease"]))
         return self.ifc(drug), self.ufc(dis)
+
+    #: f3 complement form — a relation that covers most cells of its block (the reference's label-0 slice: 89 %,
+    #: data_loader.py:146-150,170) is evaluated as `colsum - complement` over ~8x fewer edges (graph.py
+    #: HeteroGraph.fused_relations_complement).  Set False for the plain fused CSR.
+    complement_form = True
 
     #: f3 epilogue — `dropout(agg_act(sum over relations))` (layers.py:134-138) inside the kernel that
     #: writes the aggregated messages.  Needs an activation the kernels know (LeakyReLU / ReLU / none).
@@ -373,9 +410,35 @@ class GCMCLayer(nn.Module):
             width = weights[cans[0]].shape[1]
             pad = -width % 4  # keep rows 16-B aligned (341 -> 344), see GCMCGraphConv.forward
             w_cat = torch.cat([F.pad(weights[c], (0, pad)) if pad else weights[c] for c in cans], dim=1)
-            feat = torch.matmul(x, w_cat).view(x.shape[0] * len(cans), width + pad)  # rows [u][r]
             scale = torch.stack([drops[c] for c in cans], dim=1).reshape(-1)
             ci = graph[cans[0]].dstdata["ci"]
+            comp = graph.fused_relations_complement(nt) if self.complement_form and hasattr(graph, "fused_relations_complement") else None
+            if comp is not None:
+                # near-complete relation i0: A_0 H = 1 colsum(H)^T - C H.  The column sum of
+                # scale_i0 * feat_i0 becomes the feature row of ONE virtual source per block of the relation (one block
+                # for a single dataset) that every destination of the block has an edge to; everything else is the
+                # same product over ~8x fewer edges (graph.py).  The transform and the column sums are written
+                # into one buffer by _ExtendedFeat (two GEMMs, no concatenation pass).
+                csr, _, i0, blockmat = comp
+                # dropout(cj) is cj itself whenever the per-relation dropout is inactive (eval, p = 0): the column-sum
+                # coefficients and the extended scale vector are then constants of the graph — kept beside it
+                cjs = [graph[c].srcdata["cj"] for c in cans]
+                frozen = all(not self.conv.mods[c[1]].dropout.training or self.conv.mods[c[1]].dropout.p == 0 for c in cans)
+                key = tuple((id(t), t._version) for t in cjs)
+                memo = graph.__dict__.setdefault("_complement_memo", {}).get(nt) if frozen else None
+                if memo is not None and memo[0] == key:
+                    coef, scale = memo[1], memo[2]
+                else:
+                    coef = (blockmat * drops[cans[i0]].reshape(1, -1)).contiguous()
+                    scale = F.pad(scale, (0, blockmat.shape[0]), value=1.0)
+                    if frozen:
+                        graph.__dict__["_complement_memo"][nt] = (key, coef, scale, cjs)  # cjs: keeps the ids alive
+                if torch.is_grad_enabled() and (x.requires_grad or w_cat.requires_grad):
+                    feat = _ExtendedFeat.apply(x, w_cat, coef, len(cans), i0)
+                else:
+                    feat = _ExtendedFeat.build(x, w_cat, coef, len(cans), i0)
+            else:
+                feat = torch.matmul(x, w_cat).view(x.shape[0] * len(cans), width + pad)  # rows [u][r]
             if spec is not None:
                 y = ops.spmm_csr_act_dropout(csr, feat, scale, ci, spec[0], spec[1], *masks[nt])
             else:

@@ -235,18 +235,12 @@ class SlicedCSR:
 # Measured on MI355X (tools/explore.py slicedcap, 10 M edges, F=128): sliced/planned time ratio
 # 1.0 at a 6 MB table, 1.9-2.4x at 13-51 MB, 1.2x at 102 MB, 1.0 at 205 MB; 1.55x at average
 # degree 100, 0.72x at 25 (a (row, slice) segment of 3 edges is all overhead).
-FORCE_KERNEL = {"planned": "planned", "sliced": "sliced", "dense": "dense"}.get(os.environ.get("DGMI_FORCE_KERNEL", ""))
-# Dense fast path (f3): the reference's encoder graph holds EVERY train pair, both
-# labels (data_loader.py:146-150,170), so a relation slice of a real dataset is a near-complete
-# bipartite block (lrssl: 464 897 of 519 603 cells) — "a dense-block tile actually materialises"
-# (north_star), and a plain fp32 GEMM through hipBLASLt beats any gather.  Taken when at least
-# DENSE_MIN_DENSITY of the cells hold an edge and the dense matrix stays small.
-# Measured (round 2, tools/step_ab.py, in-process A/B on an lrssl-shaped model): through torch.mm the dense
-# form is SLOWER than the planned CSR kernel in context — eval forward 2.08 vs 1.93 ms, training step with
-# edge dropout +0.55 ms (the dense matrix of a dropped view is rebuilt every step) — so it is opt-in:
-# DENSE_MIN_DENSITY = 0.25 enables it (DGMI_DENSE_MIN_DENSITY); the default never selects it.
-DENSE_MIN_DENSITY = float(os.environ.get("DGMI_DENSE_MIN_DENSITY", "2.0"))
-DENSE_MAX_CELLS = 1 << 24  # 64 MB of fp32
+FORCE_KERNEL = {"planned": "planned", "sliced": "sliced"}.get(os.environ.get("DGMI_FORCE_KERNEL", ""))
+# Near-complete relation slices (f3, SURVEY §9-Q3: the reference's encoder graph holds EVERY train pair, both
+# labels, data_loader.py:146-150,170 — lrssl shape: 464 897 of 519 603 cells) are handled one level up, as the
+# COMPLEMENT form `column sum - complement cells` over the same CSR kernels (graph.py
+# HeteroGraph.fused_relations_complement): 14 us against 40 us per relation-fused product at F = 344.  The round-2
+# dense form (a materialised dense matrix through torch.mm) lost to the CSR kernel in context and was retired.
 # Round 2 (tools/cfg5_forms_probe.py): on the node-scaled config-5 shards the sliced pair still wins at
 # 204 MB / degree 100 (0.737 vs 0.784 ms) and 409 MB / degree 200 (0.739 vs 0.820 ms), and loses badly
 # once a row has few edges per slice (degree 25: 0.924 vs 0.677 ms; 12.5: 1.754 vs 0.643 ms).
@@ -515,64 +509,11 @@ class CSRGraph:
                             None if row_scale is None else row_scale.reshape(-1), out, plan, n_rows, n_cols, 0, 0,
                             eid if self._keep is not None else None, self._keep, epi)
 
-    # -- dense fast path ----------------------------------------------------------------------------
-    def _use_dense(self) -> bool:
-        S = self._S
-        cells = S.n_dst * S.n_src
-        if FORCE_KERNEL is not None:
-            return FORCE_KERNEL == "dense" and 0 < cells <= DENSE_MAX_CELLS
-        # An edge-dropped view would have to rebuild its dense matrix every training step (mask pass +
-        # 2 MB memset + scatter-add): measured 0.55 ms per lrssl-shaped step MORE than letting the CSR
-        # kernels skip the dropped edges on the fly — the dense form is for graphs that stay put.
-        return self._keep is None and 0 < cells <= DENSE_MAX_CELLS and self.nnz >= DENSE_MIN_DENSITY * cells
-
-    def _dense_matrix(self) -> torch.Tensor:
-        """A as a dense (n_dst, n_src) fp32 matrix of THIS view: entry = sum of the values (1 when
-        unweighted) of the surviving edges of that cell (duplicates add up, as in the sparse sums).
-        Built once per view — an edge-dropped view pays one mask pass, one scatter-add."""
-        A = self.__dict__.get("_dense")
-        if A is None:
-            S = self._S
-            w = self._coo_vals
-            if self._keep is not None:
-                m = keep_mask(self._keep, self.nnz)
-                w = m if w is None else w * m
-            if w is None:
-                w = torch.ones(self.nnz, dtype=torch.float32, device=S.dst.device)
-            A = torch.zeros((S.n_dst, S.n_src), dtype=torch.float32, device=S.dst.device)
-            A.index_put_((S.dst.long(), S.src.long()), w, accumulate=True)
-            self.__dict__["_dense"] = A
-        return A
-
-    def _dense_product(self, transposed: bool, X, col_scale, row_scale, out, epi=None):
-        """``diag(row_scale) M diag(col_scale) X`` with M = A or A^T as one fp32 GEMM (hipBLASLt through
-        torch.mm).  Differs from the gather kernels only where X holds Inf / NaN in rows no edge
-        touches (0 * Inf): finite inputs agree to fp32 rounding."""
-        A = self._dense_matrix()
-        M = A.t() if transposed else A
-        if col_scale is not None:
-            X = X * col_scale.reshape(-1, 1)
-        Y = torch.mm(M, X, out=out) if out is not None else torch.mm(M, X)
-        if row_scale is not None:
-            Y.mul_(row_scale.reshape(-1, 1))
-        if epi is not None:
-            act, slope, mask, mscale = epi
-            if act == 1:
-                Y = torch.nn.functional.leaky_relu_(Y, slope)
-            if mask is not None:
-                Y.mul_(mask).mul_(mscale)
-        return Y
-
     def spmm(self, X, src_scale=None, dst_scale=None, out=None, epi=None):
-        """``diag(dst_scale) A diag(src_scale) X`` (no autograd).  Picks the dense GEMM for
-        near-complete blocks, the XCD-local sliced kernel when the feature table is a few L2s large
-        and the graph is regular, else the planned kernel.  ``epi``: output epilogue
+        """``diag(dst_scale) A diag(src_scale) X`` (no autograd).  Picks the XCD-local sliced kernel when the
+        feature table is a few L2s large and the graph is regular, else the planned kernel.  ``epi``: output epilogue
         (act, slope, out_mask, mask_scale), fused into the kernel that writes the result."""
         S = self._S
-        if X.dim() == 2 and self._use_dense():
-            if not X.is_cuda or X.device != S.indptr.device:
-                _require_device(S.indptr, X)
-            return self._dense_product(False, X, src_scale, dst_scale, out, epi)
         if X.dim() == 2 and self._use_sliced(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
             if S.sliced is None:
                 S.sliced = SlicedCSR.from_csr(S.indptr, S.indices, S.eid, S.n_dst, S.n_src)  # one partition pass, no sort
@@ -588,10 +529,6 @@ class CSRGraph:
     def spmm_t(self, dY, src_scale=None, dst_scale=None, out=None):
         """``diag(src_scale) A^T diag(dst_scale) dY`` — the backward of :meth:`spmm`."""
         S = self._S
-        if dY.dim() == 2 and self._use_dense():
-            if not dY.is_cuda or dY.device != S.indptr.device:
-                _require_device(S.indptr, dY)
-            return self._dense_product(True, dY, dst_scale, src_scale, out)
         indptr_t, indices_t, eid_t, plan_t = self._t_struct()
         if S.regular_t is None:  # one-time readback of the reversed graph's maximum degree
             max_deg = int((indptr_t[1:] - indptr_t[:-1]).max()) if self.nnz else 0
@@ -648,6 +585,21 @@ class _SpMMEpilogue(torch.autograd.Function):
             g_pre = epilogue_backward(dY.contiguous(), y, mask, act, slope, mask_scale)
             dX = ctx.g.spmm_t(g_pre, src_scale, dst_scale)
         return dX, None, None, None, None, None, None, None
+
+
+def colsum_rows_(feat_ext, coef, n: int, R: int, i0: int):
+    """In place: rows ``[n*R, n*R + B)`` of ``feat_ext`` <- ``coef @ feat_ext[i0::R][:n]`` — the per-block column sums of
+    the complement form (``dgmi_weighted_colsum_f32``)."""
+    _require_device(feat_ext, coef)
+    _T.colsum_rows_(feat_ext, coef, n, R, i0)
+    return feat_ext
+
+
+def colsum_rows_backward_(gf, coef, gs, n: int, R: int, i0: int):
+    """In place: ``gf[i0::R] += coef^T @ gs`` (``dgmi_rank_add_f32``)."""
+    _require_device(gf, coef, gs)
+    _T.colsum_rows_backward_(gf, coef, gs, n, R, i0)
+    return gf
 
 
 def epilogue_backward(dY, Y, mask, act, slope, mask_scale):

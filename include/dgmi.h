@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 15
+#define DGMI_ABI_VERSION 16
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -259,6 +259,22 @@ DGMI_API int dgmi_epilogue_backward_f32(const float* dY, const float* Y, const f
                                         dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
+ * (f3) Complement form of a near-complete relation slice.  The reference's encoder graph holds
+ * every train pair, both labels (data_loader.py:146-150,170), so its label-0 slice covers ~89 % of the cells and
+ *     A_0 H = 1 colsum(H)^T - C H,    C = the cells NOT in A_0 (8x fewer),
+ * which the SpMM entry points evaluate as an ordinary signed-unit-valued CSR with one extra source row per block
+ * holding the column sum (layers.py:220-234 is what this replaces; dream_gnn_amd/graph.py builds the CSR).  Two
+ * helpers keep that extra row out of library GEMMs (M = 1 there: 34 us against 3 us):
+ *   dgmi_weighted_colsum_f32   out[b, c] = sum_u coef[b * ldc + u] * A[u * lda + c]     b < B <= 64, c < W
+ *   dgmi_rank_add_f32          G[u * ldg + c] += sum_b coef[b * ldc + u] * gs[b * lds + c]   (its backward)
+ * Fixed summation order: bitwise reproducible.
+ */
+DGMI_API int dgmi_weighted_colsum_f32(const float* A, int64_t lda, const float* coef, int64_t ldc, int64_t n,
+                                      int64_t W, int32_t B, float* out, int64_t ldo, dgmi_stream_t stream);
+DGMI_API int dgmi_rank_add_f32(float* G, int64_t ldg, const float* coef, int64_t ldc, const float* gs, int64_t lds,
+                               int64_t n, int64_t W, int32_t B, dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
  * (D3) Edge dropout selection: a uniformly random subset of exactly `keep` of E edges — what
  * `perm = randperm(E); keep = perm[:num_keep]` (augmentation.py:48-52, 114-118) selects,
  * without materialising the permutation: per-edge keys (hash32(seed, e), e) and a SELECTION of the
@@ -269,9 +285,13 @@ DGMI_API int dgmi_epilogue_backward_f32(const float* dY, const float* Y, const f
  *
  *   dgmi_random_subset_select   writes the subset's 8-word description to desc[0..7] (device):
  *                               {e_begin = e_offset, e_end = e_offset + E, seed_lo, seed_hi,
- *                               threshold hash, tie cut, 0, 0}; edge e_offset + i is kept iff
+ *                               threshold hash, tie cut, flags = 0, 0}; edge e_offset + i is kept iff
  *                               hash32(seed, i) < thr || (hash32(seed, i) == thr && i <= tie cut).
- *                               This is what the SpMM entry points take as `keep`.
+ *                               This is what the SpMM entry points take as `keep`.  A caller may set
+ *                               bit 0 of word 6 (flags) to INVERT the description: the edges it drops are
+ *                               the ones that take part (the complement form of a near-complete relation
+ *                               subtracts its dropped edges).  An edge covered by several descriptions
+ *                               takes part only if every one of them lets it (dropouts compose).
  *   dgmi_random_subset_select_batch  the same for n <= 8 edge lists with ONE series of launches (the
  *                               E / keep / seed / e_offset arrays are HOST arrays of length n, e_offset
  *                               may be NULL; descs: n x 8 words on the device): a training step selects

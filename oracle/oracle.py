@@ -286,7 +286,7 @@ def keep_mask(desc, E):
     if every one of them keeps it (csrc/dgmi_keep.h edge_kept)."""
     d = np.asarray(desc, np.int32).reshape(-1, 8).view(np.uint32).astype(np.uint64)
     mask = np.ones(E, np.float32)
-    for e_begin, e_end, lo, hi, thr, cut, _, _ in d:
+    for e_begin, e_end, lo, hi, thr, cut, flags, _ in d:
         e_begin, e_end = int(e_begin), min(int(e_end), E)
         if e_end <= e_begin:
             continue
@@ -294,6 +294,8 @@ def keep_mask(desc, E):
         h = _edge_hash((int(hi) << 32) | int(lo), n)
         cut = int(np.uint32(cut).view(np.int32)) if isinstance(cut, np.generic) else int(np.array(cut, np.uint32).view(np.int32))
         kept = (h < thr) | ((h == thr) & (np.arange(n) <= cut))
+        if int(flags) & 1:  # inverted description (kKeepInvert): the edges it drops take part
+            kept = ~kept
         mask[e_begin:e_end] *= kept.astype(np.float32)  # intersection over the covering descriptions
     return mask
 

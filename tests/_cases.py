@@ -126,7 +126,7 @@ def build_enc(g, dev):
                              symm=True, device=dev).int()
 
 
-def case_gcmc_layer(dev, name, fuse=True, device_arg=None, dropout_rate=0.0, seed=None):
+def case_gcmc_layer(dev, name, fuse=True, device_arg=None, dropout_rate=0.0, seed=None, complement=True):
     from dream_gnn_amd import layers as L
 
     g = load("gcmc_layer_" + name)
@@ -138,6 +138,7 @@ def case_gcmc_layer(dev, name, fuse=True, device_arg=None, dropout_rate=0.0, see
     layer = load_sd(layer, g, dev)
     layer.train()
     layer.fuse_relations = fuse
+    layer.complement_form = complement
     enc = build_enc(g, dev)
     drug = T(g["drug"], dev).requires_grad_(True)
     dis = T(g["dis"], dev).requires_grad_(True)
@@ -147,6 +148,10 @@ def case_gcmc_layer(dev, name, fuse=True, device_arg=None, dropout_rate=0.0, see
     ((o_drug * T(g["d_drug"], dev)).sum() + (o_dis * T(g["d_dis"], dev)).sum()).backward()
     fused = enc.__dict__.get("_fused", {})
     assert (set(fused) == {"drug", "disease"} and all(v is not None for v in fused.values())) == fuse
+    # the fixtures are reference-shaped (156 of 187 cells are train pairs, label 0 alone > 50 %): the fused path runs
+    # in complement form (graph.fused_relations_complement) unless told not to
+    comp = enc.__dict__.get("_fused_complement", {})
+    assert (set(comp) == {"drug", "disease"} and all(v is not None for v in comp.values())) == (fuse and complement)
     close(o_drug, g["o_drug"], 1e-5, "o_drug")
     close(o_dis, g["o_dis"], 1e-5, "o_dis")
     close(drug.grad, g["g_drug"], 1e-4, "g_drug")

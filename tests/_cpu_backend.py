@@ -90,6 +90,18 @@ def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan,
     return y
 
 
+def colsum_rows_(feat_ext, coef, n, R, i0):
+    W = feat_ext.shape[1]
+    feat_ext[n * R:] = coef @ feat_ext[: n * R].view(n, R, W)[:, i0, :]
+    return feat_ext
+
+
+def colsum_rows_backward_(gf, coef, gs, n, R, i0):
+    W = gf.shape[1]
+    gf.view(n, R, W)[:, i0, :] += coef.t() @ gs
+    return gf
+
+
 def epilogue_backward(dY, Y, mask, act, slope, mask_scale):
     g = torch.where(Y > 0, dY, dY * slope) if act == 1 else dY.clone()
     return g if mask is None else g * mask * mask_scale
@@ -100,7 +112,7 @@ def patched():
     from dream_gnn_amd import ops
 
     names = ("csr_from_coo", "gather_f32", "spmm_csr_raw", "_launch_spmm", "_require_device", "build_plan", "FORCE_KERNEL",
-             "gather_concat_raw", "gather_add_raw", "random_subset_mask", "random_subset_select", "random_subset_select_batch", "keep_mask", "epilogue_backward")
+             "gather_concat_raw", "gather_add_raw", "random_subset_mask", "random_subset_select", "random_subset_select_batch", "keep_mask", "epilogue_backward", "colsum_rows_", "colsum_rows_backward_")
     saved = {k: getattr(ops, k) for k in names}
     ops.csr_from_coo, ops.gather_f32, ops.spmm_csr_raw = csr_from_coo, gather_f32, spmm_csr_raw
     ops._launch_spmm = _launch_spmm
@@ -111,6 +123,8 @@ def patched():
     ops.random_subset_select_batch = random_subset_select_batch
     ops.keep_mask = keep_mask
     ops.epilogue_backward = epilogue_backward
+    ops.colsum_rows_ = colsum_rows_
+    ops.colsum_rows_backward_ = colsum_rows_backward_
     ops._require_device = lambda *ts: next((t.device for t in ts if t is not None), None)
     ops.build_plan = lambda indptr, nnz, chunk=None: None  # launch plans are a device-side concern
     ops.FORCE_KERNEL = "planned"  # the sliced layout is a device-side concern too

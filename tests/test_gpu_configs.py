@@ -79,6 +79,66 @@ def test_lrssl_slices_every_row_every_kernel(oracle, lrssl, dev, F):
                             g.spmm_t(torch.from_numpy(W).to(dev), cj, ci), "%s transpose F=%d" % (can[1], F))
 
 
+@pytest.mark.parametrize("shape", ["lrssl", "C+G"])
+@pytest.mark.parametrize("F", [344, 128])
+def test_complement_form_every_row_with_and_without_dropout(oracle, lrssl, dev, shape, F):
+    """(f3) The relation-fused aggregate in COMPLEMENT form — label-0 relation as
+    colsum - complement cells (- its dropped edges under edge dropout: description inverted, live edges
+    compacted in-wave) — against the f64 oracle of the PLAIN aggregate diag(ci) sum_r A_r diag(cj_r) X W_r,
+    every destination row, both destination types, un-dropped and with the reference's 10 % edge dropout
+    (augmentation.py:48-52), forward and transpose (through autograd, so that the virtual source's gradient
+    flows back through the column sum)."""
+    from dream_gnn_amd import graph as G, ops, synth
+
+    if shape == "lrssl":
+        enc = lrssl[0]["enc_graph"]
+    else:
+        drug, dis, labels, nd, ns = synth.dataset_shaped_pairs([synth.DATASET_SHAPES["Cdataset"], synth.DATASET_SHAPES["Gdataset"]])
+        enc = G.build_enc_graph(drug, dis, labels, nd, ns, device=dev).int()
+    rng = np.random.default_rng(F)
+    torch.manual_seed(5)
+    child = G.random_edge_dropout(enc, 0.1)
+    for g_, who in ((enc, "un-dropped"), (child, "10 % edge dropout")):
+        for nt in ("disease", "drug"):
+            full, cans = g_.fused_relations(nt)
+            comp = g_.fused_relations_complement(nt)
+            assert comp is not None and comp[1] == cans
+            ccsr, _, i0, blockmat = comp
+            R = len(cans)
+            n_src = full.n_src // R
+            cells = n_src * full.n_dst
+            if who == "un-dropped":
+                assert ccsr.nnz < 0.25 * full.nnz, (ccsr.nnz, full.nnz)  # ~8x fewer edges walked and gathered
+            X = rng.standard_normal((full.n_src, F)).astype(np.float32)
+            ss = rng.uniform(0.5, 1.5, full.n_src).astype(np.float32)
+            ds = rng.uniform(0.5, 1.5, full.n_dst).astype(np.float32)
+            W = rng.standard_normal((full.n_dst, F)).astype(np.float32)
+            # oracle of the plain aggregate over the SURVIVING edges of the fused edge list
+            S_ = full._S
+            m = full.keep_mask()
+            keep = np.ones(full.nnz, bool) if m is None else m.cpu().numpy().astype(bool)
+            dst, src = S_.dst.cpu().numpy()[keep], S_.src.cpu().numpy()[keep]
+            ip, ix, _ = oracle.csr_from_coo(dst, src, full.n_dst)
+            tp, ti, _ = oracle.csr_from_coo(src, dst, full.n_src)
+            t = lambda a: torch.from_numpy(a).to(dev)
+            xa = t(X).requires_grad_(True)
+            assert blockmat.shape == ((1 if shape == "lrssl" else 2), n_src)  # C+G merged: one column sum per dataset block
+            s_row = blockmat @ (t(ss).view(-1, R)[:, i0:i0 + 1] * xa.view(n_src, R, F)[:, i0])
+            y = ops.spmm_csr(ccsr, torch.cat([xa, s_row]), torch.cat([t(ss), torch.ones(blockmat.shape[0], device=dev)]), t(ds))
+            # the identity subtracts ~10 % of the terms from the full column sum: the error bound is the plain sum's
+            # plus the subtracted part's, i.e. at most the bound over ALL cells of relation i0 — use the oracle's
+            # sum |terms| of the plain product scaled by cells / kept (>= every term that entered)
+            ref = oracle.spmm_csr(ip, ix, None, X, ss, ds, acc="f64")
+            bound = oracle.spmm_csr(ip, ix, None, X, ss, ds, acc="abs") * (cells / max(1, keep.sum() // 1))
+            err = np.abs(y.detach().cpu().numpy().astype(np.float64) - ref)
+            assert np.all(err <= RTOL * bound + 1e-30), "%s %s ->%s F=%d: %.2e of the bound" % (shape, who, nt, F, float((err / (bound + 1e-30)).max()))
+            assert err.max() <= RTOL * np.abs(ref).max(), (shape, who, nt, F, err.max(), np.abs(ref).max())
+            y.backward(t(W))
+            ref_t = oracle.spmm_csr(tp, ti, None, W, ds, ss, acc="f64")
+            err_t = np.abs(xa.grad.cpu().numpy().astype(np.float64) - ref_t)
+            assert err_t.max() <= RTOL * np.abs(ref_t).max(), (shape, who, nt, F, "transpose", err_t.max(), np.abs(ref_t).max())
+
+
 def test_lrssl_knn4_adjacencies_every_row(oracle, lrssl, dev):
     """The four kNN-4 FGCN graphs (nnz <= 9 N) at the widths the model runs them: 768 and 128."""
     from dream_gnn_amd import layers as L
@@ -100,12 +160,13 @@ def test_lrssl_knn4_adjacencies_every_row(oracle, lrssl, dev):
             assert float((y - ref).abs().max()) <= RTOL * float(ref.abs().max())
 
 
-def _module_parity(dev, blocks, out_units, seed):
+def _module_parity(dev, blocks, out_units, seed, complement=False):
     """Net forward + loss + backward on the HIP path vs the same modules on the CPU with the
     oracle as op backend, identical parameters and inputs, no stochastic layers."""
-    from dream_gnn_amd import harness as H, model as M, synth
+    from dream_gnn_amd import harness as H, layers as L, model as M, synth
 
     res = {}
+    L.GCMCLayer.complement_form = complement
     for where in ("gpu", "cpu"):
         device = dev if where == "gpu" else torch.device("cpu")
         ctx = _cpu_backend.patched() if where == "cpu" else None
@@ -132,6 +193,7 @@ def _module_parity(dev, blocks, out_units, seed):
         finally:
             if ctx is not None:
                 ctx.__exit__(None, None, None)
+    L.GCMCLayer.complement_form = True
     (gl, gp, gg), (cl, cp, cg) = res["gpu"], res["cpu"]
     assert abs(gl - cl) <= 1e-5 * max(1.0, abs(cl)), (gl, cl)
     assert float((gp - cp).abs().max()) <= 1e-4 * float(cp.abs().max()), "logits"
@@ -139,15 +201,25 @@ def _module_parity(dev, blocks, out_units, seed):
     # parameter gradients pass through 3 layers of fp32 GEMMs whose reduction order differs between
     # hipBLASLt and MKL; bias gradients are cancelling sums over every node / pair (worst measured:
     # 2.7e-4 of the tensor's max on TGCN.2.ufc.bias at the merged shape)
+    # Complement form (f3): the label-0 relation enters as `column sum - complement`, so every destination row of a
+    # layer shares ONE rounding of that column sum (a 763-term fp32 sum, ~1e-7 relative) instead of carrying its own.
+    # The two boxes round it differently (HIP kernel order vs MKL); a shift common to all rows does not average out over
+    # the nodes the way independent per-row roundings do, and the parameters whose gradient is a near-total
+    # cancellation over all nodes (TGCN.0.basis: max 2e-3 here) see it: measured 1.7e-2 of the tensor's max, against
+    # 2.7e-4 in the plain form.  Both are fp32 evaluations of equal accuracy — against an f64 evaluation of one layer the
+    # two forms' gradients err by 8e-7 and 1.1e-6 of the max (tools/complement_check.py) — so the bound is looser here,
+    # the forward (loss, logits) is held to the same 1e-5 / 1e-4 as the plain form.
+    tol = 5e-2 if complement else 1e-3
     for k in cg:
         scale = float(cg[k].abs().max())
-        assert float((gg[k] - cg[k]).abs().max()) <= 1e-3 * scale + 1e-9, (k, scale)
+        assert float((gg[k] - cg[k]).abs().max()) <= tol * scale + 1e-9, (k, scale)
 
 
-def test_cfg2_lrssl_full_model_hip_vs_cpu_oracle_path(oracle, dev):
+@pytest.mark.parametrize("complement", [False, True])
+def test_cfg2_lrssl_full_model_hip_vs_cpu_oracle_path(oracle, dev, complement):
     from dream_gnn_amd import synth
 
-    _module_parity(dev, [synth.DATASET_SHAPES["lrssl"]], 128, seed=0)
+    _module_parity(dev, [synth.DATASET_SHAPES["lrssl"]], 128, seed=0, complement=complement)
 
 
 def test_cfg3_c_plus_g_merged_full_model_hip_vs_cpu_oracle_path(oracle, dev):

@@ -612,7 +612,7 @@ def test_batched_subset_selection_equals_single_calls(oracle, dev):
 def test_output_epilogue_in_every_kernel_form(dev, F, act, slope):
     """f3 epilogue (`dropout(agg_act(.))`, layers.py:134-138) inside the kernel that writes Y: the
     fused result equals activation + mask applied afterwards to the un-fused product, bit for bit,
-    for the wave-per-row, planned (incl. chunked long rows), XCD-sliced and dense forms; the backward
+    for the wave-per-row, planned (incl. chunked long rows) and XCD-sliced forms; the backward
     equals torch autograd of the un-fused composition."""
     from dream_gnn_amd import ops
 
@@ -642,9 +642,6 @@ def test_output_epilogue_in_every_kernel_form(dev, F, act, slope):
         forms["xcd-sliced"] = (sl.spmm(X, ss, ds), sl.spmm(X, ss, ds, epi=epi))
     for name, (plain, fused) in forms.items():
         assert torch.equal(fused, post(plain)), name
-    dense = g._dense_product(False, X, ss, ds, None, epi)
-    ref = post(forms["planned"][0])
-    assert float((dense - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
     # autograd
     x1 = X.clone().requires_grad_(True)
     y1 = ops.spmm_csr_act_dropout(g, x1, ss, ds, act, slope, mask, mscale)

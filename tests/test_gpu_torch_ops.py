@@ -98,3 +98,29 @@ def test_ops_reject_bad_arguments_with_runtime_errors(dev):
         OPS.spmm_csr_raw(i32(0, 1), i32(0), None, None, torch.zeros(1, 8, dtype=torch.int32, device=dev), X, None, None, None, 0)
     with pytest.raises(NotImplementedError):  # no CPU kernel is registered: the dispatcher says so
         OPS.gather_f32(torch.ones(3), torch.zeros(3, dtype=torch.int32))
+
+
+def test_colsum_rows_ops_match_torch(dev):
+    """(f3) dgmi_weighted_colsum_f32 / dgmi_rank_add_f32 through the dispatcher, against the GEMMs they replace."""
+    from dream_gnn_amd import ops
+
+    torch.manual_seed(2)
+    for n, R, W, B, i0 in ((763, 2, 344, 1, 0), (1256, 2, 256, 2, 0), (37, 3, 5, 3, 2), (5, 1, 128, 1, 0)):
+        feat = torch.randn(n * R + B, W, device=dev)
+        coef = torch.rand(B, n, device=dev)
+        want = (coef.double() @ feat[: n * R].view(n, R, W)[:, i0, :].double())
+        keep = feat[: n * R].clone()
+        ops.colsum_rows_(feat, coef, n, R, i0)
+        assert torch.equal(feat[: n * R], keep)
+        assert float((feat[n * R:].double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        again = feat.clone()
+        ops.colsum_rows_(again, coef, n, R, i0)
+        assert torch.equal(again, feat)  # fixed summation order
+        gf = torch.randn(n * R, W, device=dev)
+        gs = torch.randn(B, W, device=dev)
+        want_g = gf.clone().double()
+        want_g.view(n, R, W)[:, i0, :] += coef.double().t() @ gs.double()
+        ops.colsum_rows_backward_(gf, coef, gs, n, R, i0)
+        assert float((gf.double() - want_g).abs().max()) <= 1e-5 * float(want_g.abs().max())
+    with pytest.raises(RuntimeError):
+        ops.colsum_rows_(torch.randn(10, 4, device=dev), torch.rand(1, 4, device=dev), 4, 2, 0)  # 4*2 + 1 != 10

@@ -32,10 +32,12 @@ def test_gcmc_graph_conv(mode):
     C.case_gcmc_conv(CPU, mode)
 
 
-@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("fuse,complement", [(True, True), (True, False), (False, False)])
 @pytest.mark.parametrize("name", ["shared_ini", "shared_noini", "unshared", "shareflag_dimdiff"])
-def test_gcmc_layer(name, fuse):
-    C.case_gcmc_layer(CPU, name, fuse)
+def test_gcmc_layer(name, fuse, complement):
+    """fuse + complement: the near-complete label-0 relation as colsum - complement (f3) — same
+    outputs and gradients as the reference's per-slice run."""
+    C.case_gcmc_layer(CPU, name, fuse, complement=complement)
 
 
 @pytest.mark.parametrize("fuse", [True, False])
@@ -244,6 +246,25 @@ def test_edge_dropout_is_a_mask_view_with_the_same_product(selection):
     xf = torch.randn(fused_parent[0].n_src, 8)
     ref = sum(child[c].csr.spmm(xf.view(-1, len(cans), 8)[:, i].contiguous()) for i, c in enumerate(cans))
     assert torch.allclose(fused_child[0].spmm(xf), ref, atol=1e-5)
+    # complement form of the same aggregate (f3): the near-complete relation i0 enters as colsum - complement cells -
+    # its DROPPED edges (its description inverted), the other relation with its description as is
+    for g_, who in ((enc, "parent"), (child, "child")):
+        comp = g_.fused_relations_complement("disease")
+        assert comp is not None and comp[1] == cans, who
+        ccsr, _, i0, blockmat = comp
+        full = g_.fused_relations("disease")[0]
+        ss = torch.rand(full.n_src)
+        xa, xb = xf.clone().requires_grad_(True), xf.clone().requires_grad_(True)
+        s_row = blockmat @ (ss.view(-1, len(cans))[:, i0:i0 + 1] * xa.view(-1, len(cans), 8)[:, i0])
+        y_c = ops.spmm_csr(ccsr, torch.cat([xa, s_row]), torch.cat([ss, torch.ones(blockmat.shape[0])]))
+        y_f = ops.spmm_csr(full, xb, ss)
+        assert ccsr.n_src == full.n_src + blockmat.shape[0] == full.n_src + 1 and torch.allclose(y_c, y_f, atol=1e-5), who
+        w = torch.randn(full.n_dst, 8)
+        y_c.backward(w)
+        y_f.backward(w)
+        assert torch.allclose(xa.grad, xb.grad, atol=1e-5), who  # the virtual source's gradient flows back through colsum
+    assert child.fused_relations_complement("disease")[0].nnz > enc.fused_relations_complement("disease")[0].nnz  # + relation i0
+    assert child.fused_relations_complement("disease")[0].indptr is enc._complement_struct("disease", True)[0].indptr
     # dropout of a dropout falls back to materialised lists
     grand = G.random_edge_dropout(child, 0.5)
     assert not isinstance(grand["0"], G.DroppedRelation) and grand["0"].number_of_edges() == max(1, int(child["0"].number_of_edges() * 0.5))
@@ -288,6 +309,59 @@ def test_edge_dropout_is_a_mask_view_with_the_same_product(selection):
         assert torch.equal(both.keep_mask(), m) and 0 < int(m.sum()) < base.nnz // 2
         ref_ab = ops.CSRGraph(base._S.dst, base._S.src, nd, nd, vals=base._coo_vals * m)
         assert torch.allclose(both.spmm(x), ref_ab.spmm(x), atol=1e-6)
+
+
+def test_complement_form_on_a_block_diagonal_union():
+    """BASELINE config 3's shape in miniature: two datasets side by side, every train pair of each a cell of its own
+    block, nothing across.  The label-0 relation is near-complete PER BLOCK: blocks are found as connected
+    components, each gets its own column sum, and the complement aggregate equals the plain fused one (values
+    and gradients).  A graph that is not dense per block is left alone."""
+    from dream_gnn_amd import graph as G, ops
+
+    rng = np.random.default_rng(4)
+    blocks = [(9, 7), (6, 5)]
+    drug, dis, lab = [], [], []
+    d0 = s0 = 0
+    for nd, ns in blocks:
+        cells = [(d, s_) for d in range(nd) for s_ in range(ns)]
+        keep = rng.permutation(len(cells))[: int(0.9 * len(cells))]
+        for k in keep:
+            drug.append(cells[k][0] + d0)
+            dis.append(cells[k][1] + s0)
+            lab.append(1.0 if rng.random() < 0.08 else 0.0)
+        d0, s0 = d0 + nd, s0 + ns
+    drug.append(d0)  # plus an isolated pair of nodes joined by a single label-1 edge: no block of relation 0
+    dis.append(s0)
+    lab.append(1.0)
+    enc = G.build_enc_graph(torch.tensor(drug), torch.tensor(dis), torch.tensor(lab), d0 + 1, s0 + 1, device=CPU).int()
+    present = torch.zeros(s0 + 1, d0 + 1, dtype=torch.bool)
+    sel = torch.tensor(lab) == 0
+    present[torch.tensor(dis)[sel], torch.tensor(drug)[sel]] = True
+    blk_dst, blk_src, B = G._bipartite_blocks(present)
+    assert B == 2 and blk_src[:9].unique().numel() == 1 and blk_src[9:15].unique().numel() == 1 and blk_src[15] == -1
+    assert blk_dst[:7].unique().numel() == 1 and blk_dst[7:12].unique().numel() == 1 and blk_dst[12] == -1
+    assert blk_src[0] != blk_src[9] and blk_dst[0] == blk_src[0] and blk_dst[7] == blk_src[9]
+    assert G._bipartite_blocks(torch.eye(20, dtype=torch.bool)) is None  # 20 components: not a union of dense blocks
+    for nt in ("disease", "drug"):
+        full, cans = enc.fused_relations(nt)
+        ccsr, cans2, i0, blockmat = enc.fused_relations_complement(nt)
+        R = len(cans)
+        n_src = full.n_src // R
+        assert cans2 == cans and blockmat.shape == (2, n_src) and ccsr.nnz < full.nnz and ccsr.n_src == full.n_src + 2
+        xa, xb = torch.randn(full.n_src, 6).requires_grad_(True), None
+        xb = xa.detach().clone().requires_grad_(True)
+        ss, ds = torch.rand(full.n_src) + 0.5, torch.rand(full.n_dst) + 0.5
+        s_rows = blockmat @ (ss.view(-1, R)[:, i0:i0 + 1] * xa.view(n_src, R, 6)[:, i0])
+        y_c = ops.spmm_csr(ccsr, torch.cat([xa, s_rows]), torch.cat([ss, torch.ones(2)]), ds)
+        y_f = ops.spmm_csr(full, xb, ss, ds)
+        assert torch.allclose(y_c, y_f, atol=1e-5)
+        w = torch.randn_like(y_f)
+        y_c.backward(w)
+        y_f.backward(w)
+        assert torch.allclose(xa.grad, xb.grad, atol=1e-5)
+    cells = torch.from_numpy(rng.choice(30 * 30, 60, replace=False))  # 7 % of the cells, one big sparse component
+    sparse = G.build_enc_graph(cells // 30, cells % 30, torch.zeros(60), 30, 30, device=CPU).int()
+    assert sparse.fused_relations_complement("disease") is None and sparse.fused_relations_complement("drug") is None
 
 
 def test_random_subset_selection_is_exact_and_uniformish(oracle):
