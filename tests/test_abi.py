@@ -153,3 +153,27 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "libdgmi_oracle" not in src, f
+
+
+def test_integration_md_stub_matches_the_header_signatures():
+    """INTEGRATION.md §2's ctypes stub (executed verbatim on the GPU by tests/test_gpu_cabi.py) declares, for every
+    entry point it binds, exactly the argument list of dream_gnn_amd/_lib.py — which is checked against the header."""
+    from dream_gnn_amd import _lib
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# dgmi_binding\.py.*?)```", text, re.S).group(1)
+    ns = {}
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        exec(compile(block, "INTEGRATION.md:dgmi_binding.py", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    bound = [n for n in _lib.SIGNATURES if getattr(getattr(ns["lib"], n), "argtypes", None)]
+    assert {"dgmi_spmm_csr_f32", "dgmi_csr_from_coo_i32", "dgmi_csr_sliced_from_coo_i32", "dgmi_spmm_sliced_f32",
+            "dgmi_spmm_sliced_planes_bytes"} <= set(bound)
+    for n in bound:
+        res, args = _lib.SIGNATURES[n]
+        got = list(getattr(ns["lib"], n).argtypes)
+        assert [ctypes.sizeof(a) for a in got] == [ctypes.sizeof(a) for a in args], n
+        assert getattr(ns["lib"], n).restype is res or ctypes.sizeof(getattr(ns["lib"], n).restype) == ctypes.sizeof(res), n
