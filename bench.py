@@ -258,13 +258,31 @@ def n1_reference():
 
 
 def committed_traffic():
-    """Fabric bytes per launch of the dominant kernel pair from the committed rocprofv3 PMC passes."""
+    """Fabric bytes per launch of the dominant kernel pair from the committed rocprofv3 PMC passes, with
+    `traffic_stale` = the kernel sources have changed since the profile was taken (sha256 of the files the
+    profile recorded against the files this run launches from; no git needed on the GPU box)."""
+    import hashlib
+
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)
+            t = json.load(f)
     except (OSError, ValueError):
         return None
+    if "fabric_bytes_per_launch" not in t and "hbm_bytes_per_launch" in t:  # round-2 file
+        t["fabric_bytes_per_launch"] = t["hbm_bytes_per_launch"]
+    recorded = t.get("kernel_source_sha256_16")
+    stale = True  # a profile that did not record what it was taken with cannot be vouched for
+    if recorded:
+        stale = False
+        for name, digest in recorded.items():
+            try:
+                with open(os.path.join(ROOT, "dream_gnn_amd", "csrc", name), "rb") as fh:
+                    stale |= hashlib.sha256(fh.read()).hexdigest()[:16] != digest
+            except OSError:
+                stale = True
+    t["traffic_stale"] = stale
+    return t
 
 
 def probe_rates(torch, dev):
@@ -559,16 +577,21 @@ def main():
             "frac_definition": "contract: SURVEY §8(d) ALGORITHMIC bytes / launch time / HBM peak. The per-edge row re-reads "
                                "it counts are served by L2 / Infinity Cache, so it is not bounded by 1; the bounded readings "
                                "are hbm_traffic_frac and l2_gather.frac below",
-            "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),
+            "traffic": None if traffic is None else traffic.get("fabric_bytes_per_launch"),
+            "traffic_is": "bytes crossing the L2 -> memory-side (fabric) boundary per launch pair, Infinity-Cache hits included; "
+                          "the HBM-only share is not observable on gfx950 (no MALL / UMC counter): compulsory_bytes <= HBM bytes <= traffic",
             "traffic_source": None if traffic is None else
             "committed rocprofv3 PMC passes, not this run: %s; %s" % (traffic.get("source"), traffic.get("correction")),
+            "traffic_profiled_at_commit": None if traffic is None else traffic.get("profiled_at_commit"),
+            "traffic_stale": None if traffic is None else traffic.get("traffic_stale"),
+            "dram_targeted_share": None if traffic is None else traffic.get("dram_targeted_share"),
             "launches": dom_n, "avg_launch_ms": avg_launch_s * 1e3,
             "alg_bytes_per_launch": dom_b / dom_n, "compulsory_bytes_per_launch": dom_c / dom_n,
             "frac_vs_measured_copy_6.29TBps_contract_bytes": achieved / HBM_COPY_GBS,
         }
-        if traffic is not None and traffic.get("hbm_bytes_per_launch"):
-            roofline["hbm_traffic_frac"] = traffic["hbm_bytes_per_launch"] / avg_launch_s / 1e9 / HBM_PEAK_GBS
-            roofline["traffic_over_compulsory"] = traffic["hbm_bytes_per_launch"] / (dom_c / dom_n)
+        if traffic is not None and traffic.get("fabric_bytes_per_launch"):
+            roofline["hbm_traffic_frac"] = traffic["fabric_bytes_per_launch"] / avg_launch_s / 1e9 / HBM_PEAK_GBS
+            roofline["traffic_over_compulsory"] = traffic["fabric_bytes_per_launch"] / (dom_c / dom_n)
         if dom_roofs:
             peak = sum(dom_roofs) / len(dom_roofs)
             roofline["l2_gather"] = {"bound": "l2_gather", "peak": peak, "achieved": achieved, "unit": "GB/s",
