@@ -241,14 +241,29 @@ FORCE_KERNEL = {"planned": "planned", "sliced": "sliced"}.get(os.environ.get("DG
 # COMPLEMENT form `column sum - complement cells` over the same CSR kernels (graph.py
 # HeteroGraph.fused_relations_complement): 14 us against 40 us per relation-fused product at F = 344.  The round-2
 # dense form (a materialised dense matrix through torch.mm) lost to the CSR kernel in context and was retired.
-# Round 2 (tools/cfg5_forms_probe.py): on the node-scaled config-5 shards the sliced pair still wins at
-# 204 MB / degree 100 (0.737 vs 0.784 ms) and 409 MB / degree 200 (0.739 vs 0.820 ms), and loses badly
-# once a row has few edges per slice (degree 25: 0.924 vs 0.677 ms; 12.5: 1.754 vs 0.643 ms).
-SLICED_MIN_TABLE_BYTES = 10 << 20
-SLICED_MAX_TABLE_BYTES = 160 << 20
-SLICED_MIN_AVG_DEGREE = 64
-SLICED_HUGE_TABLE_BYTES = 448 << 20   # tables between MAX and HUGE: only with SLICED_HUGE_MIN_AVG_DEGREE
-SLICED_HUGE_MIN_AVG_DEGREE = 96
+# Which products take the XCD-local form: fitted to a timing sweep of every form (round 3,
+# tools/kernel_choice_sweep.py -> profiles/r03_kernel_choice_sweep.csv: F in {64, 128, 256, 344}, 20k .. 1.6M sources,
+# average degree 16 .. 400, uniform and Zipf(1.1) degrees).  The sliced pair's advantage is set by the edges per
+# (row, slice) segment — the average degree — and shrinks as the table outgrows what 8 L2s / the Infinity Cache hold:
+#   degree >= 192: up to 1.5 GB tables     degree >= 96: up to 800 MB     degree >= 48: up to 420 MB
+#   32 <= degree < 48: only where a slice is about one L2 (20 .. 80 MB tables: +7 .. 18 %)
+# and tables below 6 MB are L2-hot for every kernel.  Long-row graphs (cut into virtual rows of SPLIT_ROW_EDGES) are
+# judged by the degree of their virtual rows; their planned kernel is slower, so the split form pays from 4 MB tables
+# and up to larger ones.  Round 2's narrower rule (10-160 MB at degree >= 64) picked a form > 10 % slower than the
+# best on 63 of the sweep's 336 shapes; this one on 3 (all within 18 %, at the rule's edges).
+SLICED_MIN_TABLE_BYTES = 6_000_000
+SLICED_TIERS = ((48, 420_000_000), (96, 800_000_000), (192, 1_500_000_000))       # (average degree >=, table bytes <=)
+SLICED_LOW_DEGREE = (32, 20_000_000, 80_000_000)                                    # degree >=, table bytes in [lo, hi]
+SPLIT_MIN_TABLE_BYTES = 4_000_000
+SPLIT_TIERS = ((48, 600_000_000), (96, 1_000_000_000), (192, 1_800_000_000))
+
+
+def _table_cap(tiers, degree: float) -> int:
+    cap = 0
+    for d, c in tiers:
+        if degree >= d:
+            cap = c
+    return cap
 
 
 class _Structure:
@@ -470,22 +485,24 @@ class CSRGraph:
         if FORCE_KERNEL is not None:  # debugging / A-B aid: DGMI_FORCE_KERNEL=planned|sliced
             return FORCE_KERNEL == "sliced" and F % 4 == 0 and n_rows * SlicedCSR.N_SLICES < 2 ** 31 - 1
         table = n_cols * F * 4
-        if not (bool(regular) and F % 4 == 0 and n_rows * SlicedCSR.N_SLICES < 2 ** 31 - 1):
+        if not (bool(regular) and F % 4 == 0 and n_rows * SlicedCSR.N_SLICES < 2 ** 31 - 1) or table < SLICED_MIN_TABLE_BYTES:
             return False
-        if SLICED_MIN_TABLE_BYTES <= table <= SLICED_MAX_TABLE_BYTES:
-            return self.nnz >= SLICED_MIN_AVG_DEGREE * n_rows
-        return SLICED_MAX_TABLE_BYTES < table <= SLICED_HUGE_TABLE_BYTES and self.nnz >= SLICED_HUGE_MIN_AVG_DEGREE * n_rows
+        degree = self.nnz / max(n_rows, 1)
+        if table <= _table_cap(SLICED_TIERS, degree):
+            return True
+        lo_deg, lo, hi = SLICED_LOW_DEGREE
+        return degree >= lo_deg and lo <= table <= hi
 
     def _use_split(self, F: int, n_rows: int, n_cols: int, regular) -> bool:
-        """Long-row graphs (power laws): same table / degree criteria, rows cut into virtual rows.
+        """Long-row graphs (power laws): the same criteria on the virtual rows the split cuts.
         Only for graphs that were validated at build (the split needs one host readback)."""
         if FORCE_KERNEL is not None or regular is not False or not self._S.validated:
             return False
         table = n_cols * F * 4
         n_virtual_bound = n_rows + self.nnz // SPLIT_ROW_EDGES
-        return (F % 4 == 0 and SLICED_MIN_TABLE_BYTES <= table <= SLICED_MAX_TABLE_BYTES
-                and self.nnz >= SLICED_MIN_AVG_DEGREE * n_virtual_bound
-                and n_virtual_bound * SlicedCSR.N_SLICES < 2 ** 31 - 1)
+        if F % 4 != 0 or n_virtual_bound * SlicedCSR.N_SLICES >= 2 ** 31 - 1 or table < SPLIT_MIN_TABLE_BYTES:
+            return False
+        return table <= _table_cap(SPLIT_TIERS, self.nnz / max(n_virtual_bound, 1))
 
     def _t_struct(self):
         S = self._S

@@ -377,11 +377,19 @@ def test_csrgraph_picks_sliced_only_when_profitable(dev):
     small = ops.CSRGraph(dst[:1000] % 50, src[:1000] % 60, 50, 60)
     small.spmm(torch.randn(60, 128, device=dev))
     assert small._sliced is None
-    # a power-law graph is not "regular": never sliced
+    # the fitted rule (tools/kernel_choice_sweep.py): by average degree and table size
+    assert g._use_sliced(128, 20_000, 40_000, True) and not g._use_sliced(16, 20_000, 40_000, True)       # 20 MB / 2.5 MB at degree 100
+    assert g._use_sliced(128, 20_000, 1_500_000, True) and not g._use_sliced(128, 20_000, 1_700_000, True)  # degree 100: up to 800 MB
+    assert not g._use_sliced(128, 100_000, 40_000, True)   # degree 20: a (row, slice) segment of 2-3 edges is all overhead
+    assert g._use_sliced(128, 50_000, 100_000, True) and not g._use_sliced(128, 50_000, 300_000, True)    # degree 40: only ~L2-sized slices
+    assert not g._use_sliced(128, 20_000, 40_000, False) and not g._use_sliced(126, 20_000, 40_000, True)
+    # a power-law graph is not "regular": never the plain sliced form — its rows are cut into virtual rows first
     p = 1.0 / torch.arange(1, n_dst + 1, device=dev, dtype=torch.float64) ** 1.2
     skew = ops.CSRGraph(torch.multinomial(p / p.sum(), E, replacement=True, generator=gen).to(torch.int32), src, n_dst, n_src)
-    skew.spmm(X)
-    assert not skew.regular and skew._sliced is None
+    ys = skew.spmm(X)
+    assert not skew.regular and skew._sliced is None and skew._S.split is not None
+    ys_plain = ops.spmm_csr_raw(skew.indptr, skew.indices, None, X, plan=skew.plan)
+    assert float((ys - ys_plain).abs().max()) <= 1e-5 * float(ys_plain.abs().max())
 
 
 def test_ops_capture_into_a_hip_graph(dev):
