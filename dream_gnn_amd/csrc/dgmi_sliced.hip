@@ -138,7 +138,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
       }
       // fast path (group-uniform): all 8 edges belong to the current row -> balanced tree, no
       // per-edge boundary tests
+#ifdef DGMI_EXPERIMENT_ALWAYS_FAST  // timing-only build: every batch on the fast path (results wrong) — the slow path's price
+      if (true) {
+#else
       if (base + j + kUnroll <= next_b) {
+#endif
         if (WEIGHTED) {
 #pragma unroll
           for (int u = 0; u < kUnroll; ++u) {
