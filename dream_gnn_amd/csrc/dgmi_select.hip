@@ -5,9 +5,9 @@
 // uniformly random subset of exactly that size.  A full random permutation is a sort of E keys;
 // only the subset is needed.  Here every edge e gets the key (hash32(seed, e), e) — unique by
 // construction — and the keep-th smallest key is found by SELECTION, never by sorting:
-//   * lists up to 2^20 edges (every real dataset of the reference): one workgroup runs a 4-pass
-//     most-significant-byte radix select on its own (256-bin LDS histogram per pass, then the ties
-//     at the threshold hash) — one launch instead of eleven; at these sizes the launches were the cost;
+//   * lists up to 2^16 edges (the label-1 relations and kNN-4 graphs of the reference's datasets): one workgroup
+//     runs a 4-pass most-significant-byte radix select on its own (256-bin LDS histogram per pass, then the ties
+//     at the threshold hash) — one launch, a few microseconds;
 //   * longer lists: the hash is uniform, so the threshold lies within 8 sigma of keep / E * 2^32.
 //     ONE pass counts the hashes below that window and histograms the window (4096 bins, a few
 //     edges per bin), a second pass lists the edges of the bin that holds the keep-th key, and one
@@ -31,7 +31,11 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kSelectThreads = 1024;      // the workgroup select
 constexpr int kTieCap = 512;
-constexpr int64_t kWindowMinE = 1 << 20;  // shorter lists: one workgroup selects on its own
+// Shorter lists: one workgroup selects on its own (one launch).  Round 2 drew this line at 2^20 to save launches, but
+// a 465 k-edge list (every real dataset's label-0 relation) keeps ONE workgroup busy for 226 us while the other 255 CUs
+// idle — 0.45 ms of an lrssl-shaped training step (two selections per step, rocprofv3).  From 2^16 edges the window
+// passes (5 small launches spread over the chip) take ~20 us instead.
+constexpr int64_t kWindowMinE = 1 << 16;
 constexpr int kBins = 4096;
 constexpr int kCollCap = 1024;
 
@@ -57,6 +61,7 @@ struct BatchParams {
   int64_t keep[kMaxKeepSegs];
   uint64_t seed[kMaxKeepSegs];
   uint32_t e_offset[kMaxKeepSegs];
+  int64_t window_min;  // lists of at least this many edges take the window passes (kWindowMinE; DGMI_SELECT_WINDOW_MIN for A/B)
   int narrow;  // tests only (DGMI_SELECT_NARROW_WINDOW=1): a window of ~2 edges, so that it misses and the take-over path runs
 };
 
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(kSelectThreads) void select_or_init_kernel(BatchPar
   const int i = blockIdx.y;
   const int64_t E = p.E[i], keep = p.keep[i];
   SelectState* st = states + i;
-  if (E < kWindowMinE || keep <= 0 || keep >= E) {
+  if (E < p.window_min || keep <= 0 || keep >= E) {
     if (threadIdx.x == 0) st->mode = kDone;
     if (keep <= 0) {  // nothing kept: what the radix select arrives at for rank 0, without the passes
       if (threadIdx.x == 0) write_desc(descs + i, E, p.seed[i], p.e_offset[i], 0u, -1);
@@ -294,13 +299,15 @@ hipError_t random_subset_select_batch(int n, const int64_t* E, const int64_t* ke
                                       const uint32_t* e_offset, void* descs, void* workspace, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   BatchParams p = {};
+  const char* wmin = getenv("DGMI_SELECT_WINDOW_MIN");
+  p.window_min = wmin != nullptr && atoll(wmin) > 0 ? atoll(wmin) : kWindowMinE;
   int64_t e_max = 0;  // of the lists that take the window passes
   for (int i = 0; i < n; ++i) {
     p.E[i] = E[i];
     p.keep[i] = keep[i];
     p.seed[i] = seed[i];
     p.e_offset[i] = e_offset ? e_offset[i] : 0u;
-    if (E[i] >= kWindowMinE && keep[i] > 0 && keep[i] < E[i] && E[i] > e_max) e_max = E[i];
+    if (E[i] >= p.window_min && keep[i] > 0 && keep[i] < E[i] && E[i] > e_max) e_max = E[i];
   }
   const char* narrow = getenv("DGMI_SELECT_NARROW_WINDOW");
   p.narrow = narrow != nullptr && narrow[0] == '1';
