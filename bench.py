@@ -54,11 +54,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 HBM_COPY_GBS = 6290.0  # measured float4 copy, same table
 F = 128
 BASE_DRUG, BASE_DIS, BASE_EDGES, KNN_K = 100_000, 50_000, 10_000_000, 64
-# The GCMC product at F=128 on config 4's 25-51 MB feature tables runs as the XCD-local pair:
-# gather kernel (LPR=32, unweighted, src scale) + the 8-plane reduce (dst scale).  Its time is
-# taken with HIP events around the pair; rocprofv3's averages of the two kernels add up to it.
+# The GCMC product at F=128 on config 4's 25-51 MB feature tables runs as the XCD-local pair behind a row-scale pass:
+# scale_rows (diag(cj) X, one streaming pass) + gather kernel (unweighted) + the 8-plane reduce (dst scale).  Its time
+# is taken with HIP events around the three; rocprofv3's averages of the kernels add up to it.
 # 50k-source direction: 32-lane groups; 100k-source direction: 16-lane groups, two column passes (dgmi_sliced.hip)
-DOMINANT = "spmm_sliced_vec4_kernel<{32|16},false,true,false> + reduce_planes_kernel<true,8>"
+DOMINANT = "scale_rows_kernel<4> + spmm_sliced_vec4_kernel<{32|16},false,false,false,true> + reduce_planes_kernel<true,8>"
 
 
 def algorithmic_bytes(nnz, n_rows, weighted, n_scales_src=0, n_scales_dst=0, width=F):

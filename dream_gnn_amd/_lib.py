@@ -59,6 +59,7 @@ SIGNATURES = {
                                                  _vp]),
     "dgmi_random_subset_select_batch": (ctypes.c_int, [ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "dgmi_keep_mask_f32": (ctypes.c_int, [_vp, ctypes.c_int32, _i64, _vp, _vp]),
+    "dgmi_scale_rows_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "dgmi_weighted_colsum_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, ctypes.c_int32, _vp, _i64, _vp]),
     "dgmi_rank_add_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, ctypes.c_int32, _vp]),
 }

@@ -303,6 +303,15 @@ DGMI_API int dgmi_epilogue_backward_f32(const float* dY, const float* Y, const f
   return from_hip(dgmi::epilogue_backward_f32(dY, Y, mask, n, act, act_slope, mask_scale, out, as_stream(stream)));
 }
 
+DGMI_API int dgmi_scale_rows_f32(const float* X, int64_t ldx, const float* scale, int64_t n, int64_t F, float* out, int64_t ldo,
+                                 dgmi_stream_t stream) {
+  if (n < 0 || F < 0 || ldx < F || ldo < F) return DGMI_ERR_INVALID_ARG;
+  if (F > INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (n == 0 || F == 0) return DGMI_OK;
+  if (X == nullptr || scale == nullptr || out == nullptr) return DGMI_ERR_INVALID_ARG;
+  return from_hip(dgmi::scale_rows_f32(X, ldx, scale, n, F, out, ldo, as_stream(stream)));
+}
+
 DGMI_API int dgmi_weighted_colsum_f32(const float* A, int64_t lda, const float* coef, int64_t ldc, int64_t n, int64_t W,
                                       int32_t B, float* out, int64_t ldo, dgmi_stream_t stream) {
   if (n < 0 || W < 0 || B < 0 || B > 64 || lda < W || ldo < W || ldc < n) return DGMI_ERR_INVALID_ARG;

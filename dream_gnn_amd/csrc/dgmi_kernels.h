@@ -157,6 +157,10 @@ hipError_t weighted_colsum_f32(const float* A, int64_t lda, const float* coef, i
 hipError_t rank_add_f32(float* G, int64_t ldg, const float* coef, int64_t ldc, const float* gs, int64_t lds, int64_t n,
                         int64_t W, int B, hipStream_t s);
 
+// out = diag(scale) X, one streaming pass (dgmi_edge.hip)
+hipError_t scale_rows_f32(const float* X, int64_t ldx, const float* scale, int64_t n, int64_t F, float* out, int64_t ldo,
+                          hipStream_t s);
+
 // mask[e] = 1 for a uniformly random subset of exactly `keep` of the E edges (dgmi_select.hip)
 size_t random_subset_workspace_bytes();
 // the 8-word description (dgmi_keep.h) of a uniformly random subset of exactly `keep` of E edges

@@ -361,6 +361,18 @@ Tensor epilogue_backward(const Tensor& dY, const Tensor& Y, const OptTensor& mas
   return out;
 }
 
+// diag(scale) X in one streaming pass (ahead of an XCD-local product, see include/dgmi.h)
+Tensor scale_rows(const Tensor& X, const Tensor& scale) {
+  Dense x = dense_of(X, "X");
+  check(scale, at::kFloat, 1, "scale", x.t);
+  TORCH_CHECK(scale.numel() == x.rows, "scale has ", scale.numel(), " entries, X has ", x.rows, " rows");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(x.t.device());
+  Tensor out = at::empty({x.rows, x.F}, x.t.options());
+  check_status(dgmi_scale_rows_f32(x.t.data_ptr<float>(), x.ld, scale.data_ptr<float>(), x.rows, x.F, out.data_ptr<float>(), x.F,
+                                   stream_of(x.t)), "dgmi_scale_rows_f32");
+  return out;
+}
+
 // (f3 complement form) rows [n*R, n*R + B) of `feat_ext` <- coef @ feat_ext[u*R + i0, :] (column sums per block), in place
 void colsum_rows_(Tensor feat_ext, const Tensor& coef, int64_t n, int64_t R, int64_t i0) {
   check(feat_ext, at::kFloat, 2, "feat_ext", feat_ext);
@@ -546,6 +558,7 @@ TORCH_LIBRARY(dreamgnn_mi, m) {
         "float mask_scale=1., int column_passes=0) -> ()");
   m.def("epilogue_backward(Tensor dY, Tensor Y, Tensor? mask, int act, float slope, float mask_scale) -> Tensor");
   m.def("knn_cosine_topk(Tensor Xn, int k) -> Tensor");
+  m.def("scale_rows(Tensor X, Tensor scale) -> Tensor");
   m.def("colsum_rows_(Tensor(a!) feat_ext, Tensor coef, int n, int R, int i0) -> ()");
   m.def("colsum_rows_backward_(Tensor(a!) gf, Tensor coef, Tensor gs, int n, int R, int i0) -> ()");
   m.def("gather_f32(Tensor values, Tensor perm) -> Tensor");
@@ -569,6 +582,7 @@ TORCH_LIBRARY_IMPL(dreamgnn_mi, CUDA, m) {
   m.impl("spmm_sliced_out", spmm_sliced_out);
   m.impl("epilogue_backward", epilogue_backward);
   m.impl("knn_cosine_topk", knn_cosine_topk);
+  m.impl("scale_rows", scale_rows);
   m.impl("colsum_rows_", colsum_rows_);
   m.impl("colsum_rows_backward_", colsum_rows_backward_);
   m.impl("gather_f32", gather_f32);

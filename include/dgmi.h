@@ -259,6 +259,15 @@ DGMI_API int dgmi_epilogue_backward_f32(const float* dY, const float* Y, const f
                                         dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
+ * out[u, :] = scale[u] * X[u, :]: diag(src_scale) X as one streaming pass.  Every SpMM entry point accepts
+ * src_scale and applies it per edge; for the XCD-local form on tables of tens of MB that per-edge 4-byte gather (one
+ * more cache-line request beside the row's four, repeated per column pass) costs 8-18 % of the product — pre-scale
+ * with this call and pass src_scale = NULL instead (what dream_gnn_amd.ops.SlicedCSR does from 8 MB).  `out` may be X.
+ */
+DGMI_API int dgmi_scale_rows_f32(const float* X, int64_t ldx, const float* scale, int64_t n, int64_t F, float* out,
+                                 int64_t ldo, dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
  * (f3) Complement form of a near-complete relation slice.  The reference's encoder graph holds
  * every train pair, both labels (data_loader.py:146-150,170), so its label-0 slice covers ~89 % of the cells and
  *     A_0 H = 1 colsum(H)^T - C H,    C = the cells NOT in A_0 (8x fewer),

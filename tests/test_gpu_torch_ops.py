@@ -124,3 +124,20 @@ def test_colsum_rows_ops_match_torch(dev):
         assert float((gf.double() - want_g).abs().max()) <= 1e-5 * float(want_g.abs().max())
     with pytest.raises(RuntimeError):
         ops.colsum_rows_(torch.randn(10, 4, device=dev), torch.rand(1, 4, device=dev), 4, 2, 0)  # 4*2 + 1 != 10
+
+
+def test_scale_rows_matches_torch_and_strided_input(dev):
+    """dgmi_scale_rows_f32 (the row-scale pass ahead of XCD-local products): bit-equal to the elementwise product,
+    row-strided and unaligned inputs included."""
+    from dream_gnn_amd import _lib
+
+    ops_ = _lib.torch_ops
+    torch.manual_seed(3)
+    for n, F in ((1000, 128), (77, 341), (5, 4), (0, 8)):
+        X = torch.randn(n, F, device=dev)
+        sc = torch.rand(n, device=dev) + 0.5
+        assert torch.equal(ops_.scale_rows(X, sc), X * sc.view(-1, 1))
+        wide = torch.randn(n, F + 12, device=dev)
+        assert torch.equal(ops_.scale_rows(wide[:, 3:3 + F], sc), wide[:, 3:3 + F] * sc.view(-1, 1))
+    with pytest.raises(RuntimeError):
+        ops_.scale_rows(torch.randn(4, 8, device=dev), torch.rand(5, device=dev))

@@ -66,15 +66,16 @@ with open(os.path.join(out, tag + "_pmc_summary.csv"), "w", newline="") as fh:
 
 # dominant products (GCMC, unweighted, source-scaled): the 50k-source direction runs the 32-lane form, the
 # 100k-source direction the 16-lane form (two column passes: grid.y) — average them by launch count
-main = [r for r in rows if r["kernel"].startswith(("spmm_sliced_vec4_kernel<32, false, true, false",
-                                                   "spmm_sliced_vec4_kernel<16, false, true, false"))]
+main = [r for r in rows if r["kernel"].startswith(("spmm_sliced_vec4_kernel<32, false, false, false",
+                                                   "spmm_sliced_vec4_kernel<16, false, false, false"))]
 red = [r for r in rows if r["kernel"].startswith("reduce_planes_kernel<true")]
+pre = [r for r in rows if r["kernel"].startswith("scale_rows_kernel")]  # the row-scale pass ahead of the gather
 dom = None
 if main and red:
     n = sum(r["launches"] for r in main)
     gather = sum(r["hbm_bytes_corrected_avg"] * r["launches"] for r in main) / n
-    dom = [{"kernel": " | ".join(r["kernel"] for r in main) + " + " + red[0]["kernel"],
-            "hbm_bytes_corrected_avg": int(gather + red[0]["hbm_bytes_corrected_avg"]),
+    dom = [{"kernel": (pre[0]["kernel"] + " + " if pre else "") + " | ".join(r["kernel"] for r in main) + " + " + red[0]["kernel"],
+            "hbm_bytes_corrected_avg": int(gather + red[0]["hbm_bytes_corrected_avg"] + (pre[0]["hbm_bytes_corrected_avg"] if pre else 0)),
             "L2_hit_rate": {r["kernel"]: r["L2_hit_rate"] for r in main}}]
 def src_hashes():
     out = {}
