@@ -31,6 +31,10 @@ __device__ __forceinline__ void store_plane_row(float* p, const float4& v) {
   // one streaming 16-B store: the planes are write-once / read-once; keep them from evicting
   // the XCD's slice of X out of L2
   v4f t = {v.x, v.y, v.z, v.w};
+#ifdef DGMI_EXPERIMENT_NO_PLANE_STORES  // timing-only build: what the plane stores cost the gather kernel (results wrong)
+  if (v.x == 123456.789f) *reinterpret_cast<v4f*>(p) = t;
+  return;
+#endif
 #ifdef DGMI_PLANES_REGULAR_STORE  // A/B switch: ordinary stores run the step in 3.03 ms instead of 2.85 ms
   *reinterpret_cast<v4f*>(p) = t;
 #else

@@ -209,6 +209,15 @@ class SlicedCSR:
 
     _DEFAULT = object()
 
+    def _prescale_pays(self, table_bytes: int, one_pass: bool) -> bool:
+        """The pass moves 2 x table bytes (3.4e-13 s per byte measured), the in-kernel scale gather costs 2.7e-12 s
+        per edge and column pass: pre-scale when the table is below ~8 bytes per edge-pass (config 4: 26-51 MB against
+        10 M edges x 1-2 passes; a 400 MB table with 6 M edges keeps the in-kernel gather — the kernel-choice sweep)."""
+        if table_bytes < PRESCALE_MIN_TABLE_BYTES:
+            return False
+        passes = 1 if one_pass or self.n_dst < 32768 or table_bytes // self.n_slices <= (4 << 20) else 2  # the launcher's column-pass rule
+        return table_bytes <= 6 * int(self.indices.shape[0]) * passes
+
     def spmm(self, X, src_scale=None, dst_scale=None, out=None, vals=_DEFAULT, keep=None, epi=None, full_width=False):
         """``vals`` (in sliced order, see ``eid``) overrides the values given at construction;
         ``keep``: subset descriptions applied through ``eid`` (edge dropout on the fly); ``epi``: output
@@ -219,7 +228,7 @@ class SlicedCSR:
             _require_device(self.segptr, X)
         if X.dim() == 2 and X.shape[0] != self.n_src:
             raise RuntimeError("X has %d rows, the graph has %d source nodes" % (X.shape[0], self.n_src))
-        if src_scale is not None and X.dim() == 2 and X.shape[0] * X.shape[1] * 4 >= PRESCALE_MIN_TABLE_BYTES:
+        if src_scale is not None and X.dim() == 2 and self._prescale_pays(X.shape[0] * X.shape[1] * 4, keep is not None or full_width):
             # diag(src_scale) X as ONE streaming pass, then the un-scaled gather: inside the kernel the scale is a
             # random 4-byte load per edge (and per column pass) — one more cache-line request beside the row's four —
             # which costs the config-4 products 8-18 % (tools/scale_cost_ab.py: 0.326 -> 0.285 ms, 0.298 -> 0.283 ms
