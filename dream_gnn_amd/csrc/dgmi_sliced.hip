@@ -16,10 +16,6 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include <map>
-#include <mutex>
-#include <utility>
-
 #include "dgmi_kernels.h"
 #include "dgmi_segment.h"
 
@@ -28,9 +24,6 @@ namespace {
 
 constexpr int64_t kColumnPassMinRows = 32768;  // column passes only when a pass still has >= ~8k waves
 constexpr int kRowsPerGroup = 8;  // <= LPR (row boundaries live one per lane of the group)
-constexpr int kDefaultPipeChunks = 1;        // chunk pipeline of spmm_sliced_f32 (DGMI_SLICED_OVERLAP)
-constexpr int64_t kPipeMinChunkRows = 8192;  // a chunk's gather must still fill the chip
-constexpr int64_t kPipeReduceBlocks = 256;   // thin plane reduce beside a gather: one workgroup per CU
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -298,139 +291,69 @@ hipError_t launch_sliced(const SlicedArgs& a, int64_t row_begin, int64_t row_end
   return hipGetLastError();
 }
 
-// Side stream + events of the chunk pipeline below, one set per caller stream, created on first use and kept.
-constexpr int kMaxPipeChunks = 8;
-struct ChunkPipe {
-  hipStream_t side = nullptr;
-  hipEvent_t gathered[kMaxPipeChunks] = {};
-  hipEvent_t reduced = nullptr;
-};
-
-ChunkPipe* pipe_for(hipStream_t s) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, ChunkPipe> pipes;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = pipes.find({dev, s});
-  if (it != pipes.end()) return &it->second;
-  ChunkPipe p;
-  if (hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-  for (int i = 0; i < kMaxPipeChunks; ++i)
-    if (hipEventCreateWithFlags(&p.gathered[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&p.reduced, hipEventDisableTiming) != hipSuccess) return nullptr;
-  return &(pipes[{dev, s}] = p);
-}
-
-int lpr_for(const SlicedArgs& a) {
-  // Lane-group width = column tile.  Widest group whose last column tile is still >= 85 % used — unless
-  // the slice of X one XCD gathers from (n_src / n_slices rows x 16 LPR bytes) is larger than its 4 MiB
-  // L2: then half the width.  The column tiles are grid.y, dispatched one after the other, so the XCD
-  // sweeps its slice twice at half the footprint.  Measured at F = 128: 100k-source table (6.4 -> 3.2 MB
-  // per pass, bench.py) 0.379 -> 0.365 ms unweighted, 0.512 -> 0.464 ms kNN-64 weighted; config-5 shards
-  // (tools/cfg5_forms_probe.py) 204 MB table 0.740 -> 0.663 ms, 409 MB table 0.741 -> 0.712 ms (the halves
-  // of all 8 slices together fit the 256 MiB Infinity Cache; a quarter width gains nothing more).  A
-  // 50k-source table (already 3.2 MB per slice) loses 10-18 % when halved, so the rule is tied to the
-  // footprint; and a graph whose time is set by a few very long (virtual) rows pays their dependent gather
-  // chain once per pass (Zipf(1.2) cut into 2048-edge virtual rows: 0.47 -> 0.62 ms; at the 512 edges
-  // ops._SplitSliced uses the passes win again, 0.435 -> 0.418 ms): such a caller can ask for full width.
-  // With edge dropout on the fly every pass re-evaluates keep(eid[p]) per edge (0.386 -> 0.408 ms): full width.
-  // Half-width groups also mean half as many waves per pass (n_dst / 4 at F = 128): with few, long rows the
-  // launch no longer fills the chip (config-5 edge-scaled shard, 6250 rows of 1600 edges: 0.382 -> 0.440 ms),
-  // so the rule needs kColumnPassMinRows destination rows.
-  // DGMI_SLICED_LPR forces a width (tools).
-  const char* lpr_env = getenv("DGMI_SLICED_LPR");  // read per call: tools flip it inside one process
-  const int forced_lpr = lpr_env != nullptr ? atoi(lpr_env) : 0;
-  int lpr = pick_lpr(a.F);
-  if (lpr >= 32 && !a.full_width && a.n_keep == 0 && a.n_dst >= kColumnPassMinRows) {
-    const int64_t width = 16 * (int64_t)lpr < 4 * a.F ? 16 * (int64_t)lpr : 4 * a.F;
-    const int64_t slice_bytes = (a.n_src + a.n_slices - 1) / a.n_slices * width;
-    if (slice_bytes > (4 << 20)) lpr /= 2;
-  }
-  if (forced_lpr == 8 || forced_lpr == 16 || forced_lpr == 32 || forced_lpr == 64) lpr = forced_lpr;
-  return lpr;
-}
-
-hipError_t launch_gather(const SlicedArgs& a, int lpr, int64_t r0, int64_t r1, hipStream_t s) {
-  switch (lpr) {
-    case 8: return launch_sliced<8>(a, r0, r1, s);
-    case 16: return launch_sliced<16>(a, r0, r1, s);
-    case 32: return launch_sliced<32>(a, r0, r1, s);
-    default: return launch_sliced<64>(a, r0, r1, s);
-  }
-}
-
-hipError_t launch_reduce(const SlicedArgs& a, int64_t r0, int64_t r1, int64_t max_blocks, hipStream_t s) {
-  const int F4 = (int)(a.F / 4);
-  int64_t blocks = ((r1 - r0) * F4 + 255) / 256;
-  if (blocks > max_blocks) blocks = max_blocks;
-  const float* ds = a.dst_scale ? a.dst_scale + r0 : nullptr;
-  float* y = a.Y + r0 * a.ldy;
-  Epilogue ep = a.ep;  // rows of this chunk start at r0
-  if (ep.mask != nullptr) ep.mask += r0 * ep.ldm;
-#define DGMI_REDUCE(D, S)                                                                               \
-  hipLaunchKernelGGL((reduce_planes_kernel<D, S>), dim3((unsigned)blocks), dim3(256), 0, s, a.planes, a.ldp, \
-                     r1 - r0, F4, (int)a.n_slices, ds, y, a.ldy, ep)
-  if (a.n_slices == 8) {
-    if (ds) DGMI_REDUCE(true, 8); else DGMI_REDUCE(false, 8);
-  } else {
-    if (ds) DGMI_REDUCE(true, 0); else DGMI_REDUCE(false, 0);
-  }
-#undef DGMI_REDUCE
-  return hipGetLastError();
-}
-
 }  // namespace
 
 hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s) {
   if (a.n_dst == 0 || a.F == 0) return hipSuccess;
-  const int lpr = lpr_for(a);
-  // Chunk pipeline.  The gather kernel is bound by the L2 -> CU gather path, the plane reduce by HBM (it reads at
-  // the copy rate): run back to back they add up, although they want different resources.  The rows are cut into C
-  // chunks with plane regions of their own; the gathers run back to back on the caller's stream, the reduce of chunk c
-  // runs on a side stream as soon as chunk c is gathered — under the gather of chunk c + 1 — as a THIN grid (one
-  // workgroup per CU: enough loads in flight for HBM, one of the gather kernel's five block slots per CU); the
-  // caller's stream waits for the last reduce.  Only the last chunk's reduce is exposed.
-  const char* ov = getenv("DGMI_SLICED_OVERLAP");
-  int C = ov != nullptr ? atoi(ov) : kDefaultPipeChunks;
-  if (C > kMaxPipeChunks) C = kMaxPipeChunks;
-  const bool chunked_by_caller = a.chunk_rows > 0 && a.chunk_rows < a.n_dst;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (C > 1 && (chunked_by_caller || a.n_dst < (int64_t)C * kPipeMinChunkRows || hipStreamIsCapturing(s, &cap) != hipSuccess ||
-                cap != hipStreamCaptureStatusNone))
-    C = 1;
-  ChunkPipe* pipe = C > 1 ? pipe_for(s) : nullptr;
-  if (pipe == nullptr) {
-    // one stream: every chunk gathered then reduced (chunk_rows < n_dst: the caller sized the plane buffer for one chunk)
-    const int64_t chunk = a.chunk_rows > 0 ? a.chunk_rows : a.n_dst;
-    for (int64_t r0 = 0; r0 < a.n_dst; r0 += chunk) {
-      const int64_t r1 = r0 + chunk < a.n_dst ? r0 + chunk : a.n_dst;
-      hipError_t err = launch_gather(a, lpr, r0, r1, s);
-      if (err != hipSuccess) return err;
-      err = launch_reduce(a, r0, r1, 8192, s);
-      if (err != hipSuccess) return err;
-    }
-    return hipSuccess;
-  }
-  const char* rb = getenv("DGMI_SLICED_REDUCE_BLOCKS");
-  const int64_t thin = rb != nullptr && atoll(rb) > 0 ? atoll(rb) : kPipeReduceBlocks;
-  const int64_t chunk = ((a.n_dst + C - 1) / C + 63) / 64 * 64;
-  int c = 0;
-  for (int64_t r0 = 0; r0 < a.n_dst; r0 += chunk, ++c) {
+  const int F4 = (int)(a.F / 4);
+  // Row chunks: the 8 partial planes of a chunk (chunk_rows * n_slices * 4F bytes, <= ~32 MB) are
+  // written and read back while still resident in the 256 MiB Infinity Cache, and the same
+  // plane buffer is reused by every chunk.
+  const int64_t chunk = a.chunk_rows > 0 ? a.chunk_rows : a.n_dst;
+  for (int64_t r0 = 0; r0 < a.n_dst; r0 += chunk) {
     const int64_t r1 = r0 + chunk < a.n_dst ? r0 + chunk : a.n_dst;
-    SlicedArgs b = a;
-    b.planes = a.planes + r0 * a.n_slices * a.ldp;  // chunk c's planes: n_slices x (r1 - r0) rows, packed behind chunk c - 1's
-    hipError_t err = launch_gather(b, lpr, r0, r1, s);
+    hipError_t err;
+    // Lane-group width = column tile.  Widest group whose last column tile is still >= 85 % used — unless
+    // the slice of X one XCD gathers from (n_src / n_slices rows x 16 LPR bytes) is larger than its 4 MiB
+    // L2: then half the width.  The column tiles are grid.y, dispatched one after the other, so the XCD
+    // sweeps its slice twice at half the footprint.  Measured at F = 128: 100k-source table (6.4 -> 3.2 MB
+    // per pass, bench.py) 0.379 -> 0.365 ms unweighted, 0.512 -> 0.464 ms kNN-64 weighted; config-5 shards
+    // (tools/cfg5_forms_probe.py) 204 MB table 0.740 -> 0.663 ms, 409 MB table 0.741 -> 0.712 ms (the halves
+    // of all 8 slices together fit the 256 MiB Infinity Cache; a quarter width gains nothing more).  A
+    // 50k-source table (already 3.2 MB per slice) loses 10-18 % when halved, so the rule is tied to the
+    // footprint; and a graph whose time is set by a few very long (virtual) rows pays their dependent gather
+    // chain once per pass (Zipf(1.2) cut into 2048-edge virtual rows: 0.47 -> 0.62 ms; at the 512 edges
+    // ops._SplitSliced uses the passes win again, 0.435 -> 0.418 ms): such a caller can ask for full width.
+    // With edge dropout on the fly every pass re-evaluates keep(eid[p]) per edge (0.386 -> 0.408 ms): full width.
+    // Half-width groups also mean half as many waves per pass (n_dst / 4 at F = 128): with few, long rows the
+    // launch no longer fills the chip (config-5 edge-scaled shard, 6250 rows of 1600 edges: 0.382 -> 0.440 ms),
+    // so the rule needs kColumnPassMinRows destination rows.
+    // DGMI_SLICED_LPR forces a width (tools).
+    const char* lpr_env = getenv("DGMI_SLICED_LPR");  // read per call: tools flip it inside one process
+    const int forced_lpr = lpr_env != nullptr ? atoi(lpr_env) : 0;
+    int lpr = pick_lpr(a.F);
+    if (lpr >= 32 && !a.full_width && a.n_keep == 0 && a.n_dst >= kColumnPassMinRows) {
+      const int64_t width = 16 * (int64_t)lpr < 4 * a.F ? 16 * (int64_t)lpr : 4 * a.F;
+      const int64_t slice_bytes = (a.n_src + a.n_slices - 1) / a.n_slices * width;
+      if (slice_bytes > (4 << 20)) lpr /= 2;
+    }
+    if (forced_lpr == 8 || forced_lpr == 16 || forced_lpr == 32 || forced_lpr == 64) lpr = forced_lpr;
+    switch (lpr) {
+      case 8: err = launch_sliced<8>(a, r0, r1, s); break;
+      case 16: err = launch_sliced<16>(a, r0, r1, s); break;
+      case 32: err = launch_sliced<32>(a, r0, r1, s); break;
+      default: err = launch_sliced<64>(a, r0, r1, s); break;
+    }
     if (err != hipSuccess) return err;
-    if ((err = hipEventRecord(pipe->gathered[c], s)) != hipSuccess) return err;
-    if ((err = hipStreamWaitEvent(pipe->side, pipe->gathered[c], 0)) != hipSuccess) return err;
-    const bool last = r1 >= a.n_dst;
-    err = launch_reduce(b, r0, r1, last ? 8192 : thin, pipe->side);  // nothing runs beside the last reduce: full width
+    int64_t blocks = ((r1 - r0) * F4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    const float* ds = a.dst_scale ? a.dst_scale + r0 : nullptr;
+    float* y = a.Y + r0 * a.ldy;
+    Epilogue ep = a.ep;  // rows of this chunk start at r0
+    if (ep.mask != nullptr) ep.mask += r0 * ep.ldm;
+#define DGMI_REDUCE(D, S)                                                                               \
+  hipLaunchKernelGGL((reduce_planes_kernel<D, S>), dim3((unsigned)blocks), dim3(256), 0, s, a.planes, a.ldp, \
+                     r1 - r0, F4, (int)a.n_slices, ds, y, a.ldy, ep)
+    if (a.n_slices == 8) {
+      if (ds) DGMI_REDUCE(true, 8); else DGMI_REDUCE(false, 8);
+    } else {
+      if (ds) DGMI_REDUCE(true, 0); else DGMI_REDUCE(false, 0);
+    }
+#undef DGMI_REDUCE
+    err = hipGetLastError();
     if (err != hipSuccess) return err;
   }
-  hipError_t err = hipEventRecord(pipe->reduced, pipe->side);
-  if (err != hipSuccess) return err;
-  return hipStreamWaitEvent(s, pipe->reduced, 0);
+  return hipSuccess;
 }
 
 }  // namespace dgmi
