@@ -724,3 +724,47 @@ def test_screened_knn_recomputes_overflowing_rows_exactly(dev):
         want = torch.topk(sim, k, dim=1).values
         assert float((got - want).abs().max()) <= 2e-6
         assert all(len(set(r.tolist())) == k for r in nbr[2990:3410].cpu())
+
+
+def test_compaction_invert_and_nested_descriptions_randomized(oracle, dev):
+    """(r3) The on-the-fly dropout path after round 3 — survivors compacted to the front of every 64-id batch, INVERTED
+    descriptions (the complement form subtracts a relation's dropped edges), several descriptions over the same edges
+    ANDed — on 80 random small shapes: odd widths (dword kernel), rows shorter / longer than a batch, keep = 0 and
+    keep = E, empty rows, planned and wave-per-row launches, against the oracle on exactly the surviving edges."""
+    from dream_gnn_amd import ops
+
+    rng = np.random.default_rng(2026)
+    for case in range(80):
+        n_dst, n_src = int(rng.integers(1, 40)), int(rng.integers(1, 60))
+        E = int(rng.integers(1, 900))
+        F = int(rng.choice([1, 3, 4, 7, 8, 12, 33, 64, 65, 128]))
+        dst = rng.integers(0, n_dst, E).astype(np.int32)
+        if case % 5 == 0:
+            dst[: E // 2] = 0  # one row far longer than a 64-id batch
+        src = rng.integers(0, n_src, E).astype(np.int32)
+        weighted = bool(case % 2)
+        vals = rng.standard_normal(E).astype(np.float32) if weighted else None
+        X = rng.standard_normal((n_src, F)).astype(np.float32)
+        ss = rng.uniform(0.5, 1.5, n_src).astype(np.float32) if case % 3 else None
+        ds = rng.uniform(0.5, 1.5, n_dst).astype(np.float32) if case % 4 else None
+        keep1 = int(rng.choice([0, 1, E // 3, E - 1, E])) if case % 7 == 0 else int(rng.integers(0, E + 1))
+        d1 = oracle.random_subset_select(E, keep1, 100 + case, 0).copy()
+        descs = [d1]
+        if case % 3 == 0:  # inverted: the edges the description drops take part
+            d1[6] = 1
+        if case % 4 == 1:  # a second description over the same edges: intersection
+            descs.append(oracle.random_subset_select(E, int(rng.integers(0, E + 1)), 500 + case, 0).copy())
+        table = np.stack(descs)
+        mask = oracle.keep_mask(table, E).astype(bool)
+        t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+        g = ops.CSRGraph(t(dst), t(src), n_dst, n_src, vals=t(vals))
+        keep_t = t(table)
+        assert np.array_equal(ops.keep_mask(keep_t, E).cpu().numpy().astype(bool), mask), case
+        ip, ix, e0 = oracle.csr_from_coo(dst[mask], src[mask], n_dst)
+        v0 = None if vals is None else vals[mask][e0]
+        ref = oracle.spmm_csr(ip, ix, v0, X, ss, ds, acc="f64")
+        bound = oracle.spmm_csr(ip, ix, v0, X, ss, ds, acc="abs")
+        for plan in (None, g.plan):
+            y = ops.spmm_csr_raw(g.indptr, g.indices, g.vals, t(X), t(ss), t(ds), plan=plan, eid=g.eid, keep=keep_t)
+            err = np.abs(y.cpu().numpy().astype(np.float64) - ref)
+            assert np.all(err <= RTOL * bound + 1e-30), (case, "planned" if plan is not None else "wave-per-row", F, E, keep1)
