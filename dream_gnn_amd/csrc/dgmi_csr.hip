@@ -6,19 +6,20 @@
 // th.spmm (layers.py:312) for the shuffled COO of augmentation.py:117-124.
 //
 // Pipeline (all on `stream`, no host sync, no atomics -> bit-exact & reproducible):
-//   1. iota + range check : tmp_eid[e] = e ; flag |= row[e] outside [0, n_rows) or col[e] outside [0, n_cols)
-//   2. stable LSD radix sort of (row, e) pairs on the low ceil(log2 n_rows) bits
-//      — rocPRIM's device radix sort (a plain library primitive; stability is
-//      what makes eid the original order inside a row)
-//   3. row boundaries     : thread p in [0, E] compares sorted_row[p-1] / [p] and
-//      writes indptr[r] = p for every r in (prev, cur] — also fills empty rows
-//   4. gather             : indices[p] = col[eid[p]]
+//   1. stable LSD radix sort of the records (row, e, col) on the low ceil(log2 n_rows) bits — the hand-written
+//      sort of dgmi_sort.hip (<= 9-bit digits, the id range check and the iota of e folded into its first pass,
+//      the column carried as payload so that no gather pass follows); stability is what makes eid the original
+//      order inside a row
+//   2. row boundaries : thread p in [0, E] compares sorted_row[p-1] / [p] and writes indptr[r] = p for every r in
+//      (prev, cur] — also fills empty rows
+// The source-sliced layouts use the same two steps on the key slice * n_rows + row (from COO), or ONE sort pass on
+// the slice bits of an existing CSR, whose positions are already in (row, input) order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "dgmi_kernels.h"
 
@@ -26,42 +27,6 @@ namespace dgmi {
 namespace {
 
 constexpr int kBlock = 256;
-
-__global__ __launch_bounds__(kBlock) void iota_check_kernel(const int32_t* __restrict__ row,
-                                                            const int32_t* __restrict__ col,
-                                                            int64_t E, int32_t n_rows, int32_t n_cols,
-                                                            int32_t* __restrict__ tmp_eid,
-                                                            int32_t* __restrict__ flag) {
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  bool bad = false;
-  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += stride) {
-    tmp_eid[e] = (int32_t)e;
-    const int32_t r = row[e];
-    bad |= (r < 0) | (r >= n_rows);
-    if (n_cols > 0) {
-      const int32_t c = col[e];
-      bad |= (c < 0) | (c >= n_cols);
-    }
-  }
-  if (bad) *flag = 1;  // benign race: every writer stores the same value
-}
-
-__global__ __launch_bounds__(kBlock) void boundaries_gather_kernel(
-    const int32_t* __restrict__ sorted_row, const int32_t* __restrict__ eid,
-    const int32_t* __restrict__ col, int64_t E, int32_t n_rows,
-    int32_t* __restrict__ indptr, int32_t* __restrict__ indices) {
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p <= E; p += stride) {
-    // rows in (prev, cur] start at p.  Out-of-range ids (flagged in step 1) are
-    // clamped so no store leaves indptr[0..n_rows].
-    int32_t prev = p > 0 ? sorted_row[p - 1] : -1;
-    int32_t cur = p < E ? sorted_row[p] : n_rows;
-    prev = max(-1, min(prev, n_rows));
-    cur = max(-1, min(cur, n_rows));
-    for (int32_t r = prev + 1; r <= cur; ++r) indptr[r] = (int32_t)p;
-    if (p < E) indices[p] = col[eid[p]];
-  }
-}
 
 __global__ __launch_bounds__(kBlock) void gather_f32_kernel(const float* __restrict__ in,
                                                             const int32_t* __restrict__ perm,
@@ -86,6 +51,47 @@ inline int bits_for(int64_t n_rows) {
   return b;
 }
 
+// ptr[k] = first sorted position whose key is >= k, for k in [0, n_keys]: row boundaries (and every empty row in
+// between).  split_bits > 0: the sorted key is (slice << split_bits) | row and stands for slice * n_rows + row.
+// A long run of empty keys (edges confined to a few rows of a large range, an empty trailing slice) is filled by the
+// whole wave, not by the one lane that found it: 6 M empty keys cost one lane 115 ms.
+constexpr int kLongGap = 64;
+__global__ __launch_bounds__(kBlock) void boundaries_kernel(const int32_t* __restrict__ sorted_key, int64_t E, int32_t n_rows,
+                                                            int split_bits, int32_t n_keys, int32_t* __restrict__ ptr) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int lane = threadIdx.x & 63;
+  const int32_t mask = split_bits > 0 ? (1 << split_bits) - 1 : -1;
+  for (int64_t p0 = (int64_t)blockIdx.x * kBlock + (threadIdx.x - lane); p0 <= E; p0 += stride) {  // wave-uniform
+    const int64_t p = p0 + lane;
+    int32_t prev = 0, cur = -1;  // lanes past E: nothing to fill
+    if (p <= E) {
+      prev = -1;
+      cur = n_keys;
+      if (p > 0) {
+        const int32_t k = sorted_key[p - 1];
+        prev = split_bits > 0 ? (k >> split_bits) * n_rows + (k & mask) : k;
+      }
+      if (p < E) {
+        const int32_t k = sorted_key[p];
+        cur = split_bits > 0 ? (k >> split_bits) * n_rows + (k & mask) : k;
+      }
+      // out-of-range ids (flagged) are clamped so that no store leaves ptr[0..n_keys]
+      prev = max(-1, min(prev, n_keys));
+      cur = max(-1, min(cur, n_keys));
+    }
+    const bool is_long = cur - prev > kLongGap;
+    if (!is_long)
+      for (int32_t r = prev + 1; r <= cur; ++r) ptr[r] = (int32_t)p;
+    uint64_t todo = __ballot(is_long);
+    while (todo) {
+      const int l = __ffsll((unsigned long long)todo) - 1;
+      todo &= todo - 1;
+      const int32_t pv = __shfl(prev, l), cu = __shfl(cur, l), pp = __shfl((int32_t)p, l);
+      for (int32_t r = pv + 1 + lane; r <= cu; r += 64) ptr[r] = pp;
+    }
+  }
+}
+
 }  // namespace
 
 hipError_t csr_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
@@ -93,44 +99,25 @@ hipError_t csr_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
                             int32_t* eid, void* workspace, size_t* workspace_bytes,
                             hipStream_t s) {
   const int end_bit = bits_for(n_rows);
-  size_t sort_bytes = 0;
-  if (E > 0) {
-    hipError_t err = rocprim::radix_sort_pairs(
-        nullptr, sort_bytes, reinterpret_cast<const uint32_t*>(row),
-        static_cast<uint32_t*>(nullptr), static_cast<const int32_t*>(nullptr), eid,
-        (size_t)E, 0u, (unsigned)end_bit, s);
-    if (err != hipSuccess) return err;
-  }
-  const size_t off_flag = 0;
-  const size_t off_keys = 256;
-  const size_t off_iota = off_keys + align_up((size_t)E * 4, 256);
-  const size_t off_sort = off_iota + align_up((size_t)E * 4, 256);
-  const size_t total = off_sort + align_up(sort_bytes, 256);
+  // hand-written sort: records (row, e, col) in up to 9-bit digits, id range check folded into the first pass
+  // (dgmi_sort.hip); the boundary pass only reads the sorted rows — the columns arrive sorted
+  const size_t off_flag = 0, off_keys = 256;
+  const size_t off_sort = off_keys + align_up((size_t)E * 4, 256);
+  const size_t total = off_sort + radix_sort_workspace_bytes(E, end_bit);
   if (workspace == nullptr) {
     *workspace_bytes = total;
     return hipSuccess;
   }
   if (*workspace_bytes < total) return hipErrorInvalidValue;
-
   char* ws = static_cast<char*>(workspace);
   int32_t* flag = reinterpret_cast<int32_t*>(ws + off_flag);
   int32_t* keys_out = reinterpret_cast<int32_t*>(ws + off_keys);
-  int32_t* tmp_eid = reinterpret_cast<int32_t*>(ws + off_iota);
-  void* sort_tmp = ws + off_sort;
-
   hipError_t err = hipMemsetAsync(flag, 0, 256, s);
   if (err != hipSuccess) return err;
-  if (E > 0) {
-    hipLaunchKernelGGL(iota_check_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, row, col, E,
-                       (int32_t)n_rows, (int32_t)n_cols, tmp_eid, flag);
-    err = rocprim::radix_sort_pairs(sort_tmp, sort_bytes, reinterpret_cast<const uint32_t*>(row),
-                                    reinterpret_cast<uint32_t*>(keys_out),
-                                    static_cast<const int32_t*>(tmp_eid), eid, (size_t)E, 0u,
-                                    (unsigned)end_bit, s);
-    if (err != hipSuccess) return err;
-  }
-  hipLaunchKernelGGL(boundaries_gather_kernel, dim3(grid_for(E + 1)), dim3(kBlock), 0, s,
-                     keys_out, eid, col, E, (int32_t)n_rows, indptr, indices);
+  err = radix_sort_records(row, nullptr, col, E, 0, end_bit, (int32_t)n_rows, (int32_t)n_cols, keys_out, eid, indices, flag,
+                           ws + off_sort, s);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(boundaries_kernel, dim3(grid_for(E + 1)), dim3(kBlock), 0, s, keys_out, E, (int32_t)n_rows, 0, (int32_t)n_rows, indptr);
   return hipGetLastError();
 }
 
@@ -146,12 +133,10 @@ __global__ __launch_bounds__(kBlock) void slice_key_kernel(const int32_t* __rest
                                                            int32_t n_rows, int32_t n_cols,
                                                            int32_t n_slices, int32_t slice_width,
                                                            int32_t* __restrict__ key,
-                                                           int32_t* __restrict__ tmp_eid,
                                                            int32_t* __restrict__ flag) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   bool bad = false;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += stride) {
-    tmp_eid[e] = (int32_t)e;
     int32_t r = row[e], c = col[e];
     const bool oob = (r < 0) | (r >= n_rows) | (c < 0) | (c >= n_cols);
     bad |= oob;
@@ -170,19 +155,11 @@ hipError_t csr_sliced_from_coo_i32(const int32_t* row, const int32_t* col, int64
                                    size_t* workspace_bytes, hipStream_t s) {
   const int64_t n_keys = n_rows * n_slices;
   const int end_bit = bits_for(n_keys);
-  size_t sort_bytes = 0;
-  if (E > 0) {
-    hipError_t err = rocprim::radix_sort_pairs(
-        nullptr, sort_bytes, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
-        static_cast<const int32_t*>(nullptr), eid, (size_t)E, 0u, (unsigned)end_bit, s);
-    if (err != hipSuccess) return err;
-  }
   const size_t off_flag = 0;
   const size_t off_keys_in = 256;
   const size_t off_keys = off_keys_in + align_up((size_t)E * 4, 256);
-  const size_t off_iota = off_keys + align_up((size_t)E * 4, 256);
-  const size_t off_sort = off_iota + align_up((size_t)E * 4, 256);
-  const size_t total = off_sort + align_up(sort_bytes, 256);
+  const size_t off_sort = off_keys + align_up((size_t)E * 4, 256);
+  const size_t total = off_sort + radix_sort_workspace_bytes(E, end_bit);
   if (workspace == nullptr) {
     *workspace_bytes = total;
     return hipSuccess;
@@ -192,22 +169,15 @@ hipError_t csr_sliced_from_coo_i32(const int32_t* row, const int32_t* col, int64
   int32_t* flag = reinterpret_cast<int32_t*>(ws + off_flag);
   int32_t* keys_in = reinterpret_cast<int32_t*>(ws + off_keys_in);
   int32_t* keys_out = reinterpret_cast<int32_t*>(ws + off_keys);
-  int32_t* tmp_eid = reinterpret_cast<int32_t*>(ws + off_iota);
-  void* sort_tmp = ws + off_sort;
   hipError_t err = hipMemsetAsync(flag, 0, 256, s);
   if (err != hipSuccess) return err;
   if (E > 0) {
     hipLaunchKernelGGL(slice_key_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, row, col, E,
-                       (int32_t)n_rows, (int32_t)n_cols, (int32_t)n_slices, (int32_t)slice_width,
-                       keys_in, tmp_eid, flag);
-    err = rocprim::radix_sort_pairs(sort_tmp, sort_bytes, reinterpret_cast<const uint32_t*>(keys_in),
-                                    reinterpret_cast<uint32_t*>(keys_out),
-                                    static_cast<const int32_t*>(tmp_eid), eid, (size_t)E, 0u,
-                                    (unsigned)end_bit, s);
+                       (int32_t)n_rows, (int32_t)n_cols, (int32_t)n_slices, (int32_t)slice_width, keys_in, flag);
+    err = radix_sort_records(keys_in, nullptr, col, E, 0, end_bit, 0, 0, keys_out, eid, indices, flag, ws + off_sort, s);
     if (err != hipSuccess) return err;
   }
-  hipLaunchKernelGGL(boundaries_gather_kernel, dim3(grid_for(E + 1)), dim3(kBlock), 0, s, keys_out,
-                     eid, col, E, (int32_t)n_keys, segptr, indices);
+  hipLaunchKernelGGL(boundaries_kernel, dim3(grid_for(E + 1)), dim3(kBlock), 0, s, keys_out, E, (int32_t)n_keys, 0, (int32_t)n_keys, segptr);
   return hipGetLastError();
 }
 
@@ -218,57 +188,32 @@ hipError_t csr_sliced_from_coo_i32(const int32_t* row, const int32_t* col, int64
 // the composite key, and the index / edge-id gathers read near-sequentially (the positions of a slice
 // are increasing).  Bit-identical to csr_sliced_from_coo_i32 on the same edge list.
 namespace {
-__global__ __launch_bounds__(kBlock) void slice_of_position_kernel(const int32_t* __restrict__ indices, int64_t E,
-                                                                   int32_t n_cols, int32_t n_slices, int32_t slice_width,
-                                                                   uint32_t* __restrict__ key, int32_t* __restrict__ pos,
-                                                                   int32_t* __restrict__ flag) {
+// key of CSR position p: (slice of its column << row_bits) | its row (binary search in indptr)
+__global__ __launch_bounds__(kBlock) void position_key_kernel(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                              int64_t E, int32_t n_rows, int32_t n_cols, int32_t n_slices,
+                                                              int32_t slice_width, int row_bits, int32_t* __restrict__ key,
+                                                              int32_t* __restrict__ flag) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   bool bad = false;
   for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < E; p += stride) {
-    pos[p] = (int32_t)p;
     int32_t c = indices[p];
     const bool oob = (c < 0) | (c >= n_cols);
     bad |= oob;
     if (oob) c = 0;
     int32_t sl = c / slice_width;
     if (sl >= n_slices) sl = n_slices - 1;
-    key[p] = (uint32_t)sl;
-  }
-  if (bad) *flag = 1;
-}
-
-// i-th entry of the sliced order: CSR position pos[i]; its row by binary search in indptr
-__global__ __launch_bounds__(kBlock) void sliced_from_csr_gather_kernel(
-    const uint32_t* __restrict__ slice_sorted, const int32_t* __restrict__ pos, const int32_t* __restrict__ indptr,
-    const int32_t* __restrict__ indices, const int32_t* __restrict__ eid, int64_t E, int32_t n_rows,
-    int32_t* __restrict__ full_key, int32_t* __restrict__ s_indices, int32_t* __restrict__ s_eid) {
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < E; i += stride) {
-    const int32_t p = pos[i];
-    int32_t lo = 0, hi = n_rows;  // first j in (0, n_rows] with indptr[j] > p; the row is j - 1
+    int32_t lo = 0, hi = n_rows;  // first j with indptr[j + 1] > p: the row of position p
     while (lo < hi) {
       const int32_t mid = (lo + hi) >> 1;
-      if (indptr[mid + 1] > p)
+      if (indptr[mid + 1] > (int32_t)p)
         hi = mid;
       else
         lo = mid + 1;
     }
-    full_key[i] = (int32_t)slice_sorted[i] * n_rows + lo;
-    s_indices[i] = indices[p];
-    s_eid[i] = eid[p];
+    if (lo >= n_rows) lo = n_rows - 1;  // an indptr that does not cover E positions (garbage in): stay in range
+    key[p] = (sl << row_bits) | lo;
   }
-}
-
-__global__ __launch_bounds__(kBlock) void boundaries_kernel(const int32_t* __restrict__ sorted_key, int64_t E, int32_t n_keys,
-                                                            int32_t* __restrict__ ptr) {
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p <= E; p += stride) {
-    int32_t prev = p > 0 ? sorted_key[p - 1] : -1;
-    int32_t cur = p < E ? sorted_key[p] : n_keys;
-    prev = max(-1, min(prev, n_keys));
-    cur = max(-1, min(cur, n_keys));
-    for (int32_t r = prev + 1; r <= cur; ++r) ptr[r] = (int32_t)p;
-  }
+  if (bad) *flag = 1;
 }
 }  // namespace
 
@@ -276,21 +221,12 @@ hipError_t csr_sliced_from_csr_i32(const int32_t* indptr, const int32_t* indices
                                    int64_t n_rows, int64_t n_cols, int64_t n_slices, int64_t slice_width, int32_t* segptr,
                                    int32_t* s_indices, int32_t* s_eid, void* workspace, size_t* workspace_bytes,
                                    hipStream_t s) {
-  const int end_bit = bits_for(n_slices);
-  size_t sort_bytes = 0;
-  if (E > 0) {
-    hipError_t err = rocprim::radix_sort_pairs(nullptr, sort_bytes, static_cast<const uint32_t*>(nullptr),
-                                               static_cast<uint32_t*>(nullptr), static_cast<const int32_t*>(nullptr),
-                                               s_eid, (size_t)E, 0u, (unsigned)end_bit, s);
-    if (err != hipSuccess) return err;
-  }
+  const int slice_bits = bits_for(n_slices), row_bits = bits_for(n_rows);  // n_rows * n_slices < 2^31 (checked by the ABI)
   const size_t off_flag = 0;
-  const size_t off_key_in = 256;  // slice of each CSR position; reused for the composite key after the sort
+  const size_t off_key_in = 256;
   const size_t off_key_out = off_key_in + align_up((size_t)E * 4, 256);
-  const size_t off_pos_in = off_key_out + align_up((size_t)E * 4, 256);
-  const size_t off_pos_out = off_pos_in + align_up((size_t)E * 4, 256);
-  const size_t off_sort = off_pos_out + align_up((size_t)E * 4, 256);
-  const size_t total = off_sort + align_up(sort_bytes, 256);
+  const size_t off_sort = off_key_out + align_up((size_t)E * 4, 256);
+  const size_t total = off_sort + radix_sort_workspace_bytes(E, slice_bits);
   if (workspace == nullptr) {
     *workspace_bytes = total;
     return hipSuccess;
@@ -298,24 +234,20 @@ hipError_t csr_sliced_from_csr_i32(const int32_t* indptr, const int32_t* indices
   if (*workspace_bytes < total) return hipErrorInvalidValue;
   char* ws = static_cast<char*>(workspace);
   int32_t* flag = reinterpret_cast<int32_t*>(ws + off_flag);
-  uint32_t* key_in = reinterpret_cast<uint32_t*>(ws + off_key_in);
-  uint32_t* key_out = reinterpret_cast<uint32_t*>(ws + off_key_out);
-  int32_t* pos_in = reinterpret_cast<int32_t*>(ws + off_pos_in);
-  int32_t* pos_out = reinterpret_cast<int32_t*>(ws + off_pos_out);
+  int32_t* key_in = reinterpret_cast<int32_t*>(ws + off_key_in);
+  int32_t* key_out = reinterpret_cast<int32_t*>(ws + off_key_out);
   hipError_t err = hipMemsetAsync(flag, 0, 256, s);
   if (err != hipSuccess) return err;
   const int32_t n_keys = (int32_t)(n_rows * n_slices);
   if (E > 0) {
-    hipLaunchKernelGGL(slice_of_position_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, indices, E, (int32_t)n_cols,
-                       (int32_t)n_slices, (int32_t)slice_width, key_in, pos_in, flag);
-    err = rocprim::radix_sort_pairs(ws + off_sort, sort_bytes, key_in, key_out, pos_in, pos_out, (size_t)E, 0u,
-                                    (unsigned)end_bit, s);
+    hipLaunchKernelGGL(position_key_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, indptr, indices, E, (int32_t)n_rows,
+                       (int32_t)n_cols, (int32_t)n_slices, (int32_t)slice_width, row_bits, key_in, flag);
+    // ONE pass on the slice bits: the CSR is already in (row, input) order, the records carry eid and column along
+    err = radix_sort_records(key_in, eid, indices, E, row_bits, slice_bits, 0, 0, key_out, s_eid, s_indices, flag, ws + off_sort, s);
     if (err != hipSuccess) return err;
-    hipLaunchKernelGGL(sliced_from_csr_gather_kernel, dim3(grid_for(E)), dim3(kBlock), 0, s, key_out, pos_out, indptr, indices,
-                       eid, E, (int32_t)n_rows, reinterpret_cast<int32_t*>(key_in), s_indices, s_eid);
   }
-  hipLaunchKernelGGL(boundaries_kernel, dim3(grid_for(E + 1)), dim3(kBlock), 0, s, reinterpret_cast<const int32_t*>(key_in), E,
-                     n_keys, segptr);
+  hipLaunchKernelGGL(boundaries_kernel, dim3(grid_for(E + 1)), dim3(kBlock), 0, s, key_out, E, (int32_t)n_rows, row_bits, n_keys,
+                     segptr);
   return hipGetLastError();
 }
 

@@ -102,6 +102,18 @@ hipError_t csr_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
                             int32_t* eid, void* workspace, size_t* workspace_bytes,
                             hipStream_t s);
 
+// Stable LSD radix sort of the records (key[i], eid[i] or i, col[i]) by bits [shift0, shift0 + bits) of the key
+// (dgmi_sort.hip): digits of up to 9 bits; n_rows / n_cols > 0: the id range check rides on the first pass.
+// Workspace: radix_sort_workspace_bytes(E, bits).
+struct SortPassPlan {
+  int shift[8], bits[8];
+};
+int radix_sort_passes(int shift0, int bits, SortPassPlan* plan);
+size_t radix_sort_workspace_bytes(int64_t E, int bits);
+hipError_t radix_sort_records(const int32_t* key, const int32_t* eid_in, const int32_t* col, int64_t E, int shift0, int bits,
+                              int32_t n_rows, int32_t n_cols, int32_t* keys_out, int32_t* eid_out, int32_t* col_out, int32_t* flag,
+                              void* workspace, hipStream_t s);
+
 // Source-sliced CSR (dgmi_csr.hip) and the XCD-local SpMM over it (dgmi_sliced.hip).
 hipError_t csr_sliced_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E, int64_t n_rows,
                                    int64_t n_cols, int64_t n_slices, int64_t slice_width,

@@ -336,6 +336,43 @@ def test_sliced_layout_from_csr_is_bit_identical(oracle, dev, shape, n_slices):
     assert np.array_equal(b.eid.cpu().numpy(), e)
 
 
+@pytest.mark.parametrize("shape", [
+    (300, 200, 8191), (300, 200, 8192), (300, 200, 8193), (513, 90, 16385),      # tile edges, 1 and 2 digit passes
+    (300_000, 1000, 70_001), (2_000_000, 10, 300_000),                          # 3 digit passes; empty trailing slices
+    (1_000_000, 700, 50_000, "few_rows"), (40, 40, 200_000, "one_row"), (7, 9, 1)])
+def test_record_sort_builds_every_layout_bit_exact(oracle, dev, shape):
+    """(f1) the hand-written record radix sort (`csrc/dgmi_sort.hip`) behind all three builders: CSR, sliced from COO,
+    sliced from the CSR == the oracle's stable sorts, bit for bit — at tile edges (8192 records per tile), at 1 / 2 / 3
+    digit passes, with every edge in one row (one digit bucket takes everything), and with long runs of empty keys
+    (edges confined to a few rows of a 10^6-row range; empty trailing slices — the runs the boundary pass fills
+    wave-wide)."""
+    from dream_gnn_amd import ops
+
+    n_dst, n_src, E = shape[:3]
+    kind = shape[3] if len(shape) > 3 else ""
+    rng = np.random.default_rng(E)
+    dst = rng.integers(0, n_dst, E).astype(np.int32)
+    src = rng.integers(0, n_src, E).astype(np.int32)
+    if kind == "few_rows":
+        dst = (rng.integers(0, 5, E) * 199_999 + 17).astype(np.int32)
+    if kind == "one_row":
+        dst[:] = 33
+    d, s_ = torch.from_numpy(dst).to(dev), torch.from_numpy(src).to(dev)
+    indptr, indices, eid, flag = ops.csr_from_coo(d, s_, n_dst, n_src, return_flag=True)
+    ip, ix, e = oracle.csr_from_coo(dst, src, n_dst)
+    assert int(flag) == 0
+    assert np.array_equal(indptr.cpu().numpy(), ip) and np.array_equal(indices.cpu().numpy(), ix)
+    assert np.array_equal(eid.cpu().numpy(), e)
+    for n_slices in (8, 64) if n_dst * 64 < 2**26 else (8,):
+        a = ops.SlicedCSR(d, s_, n_dst, n_src, n_slices=n_slices)
+        b = ops.SlicedCSR.from_csr(indptr, indices, eid, n_dst, n_src, n_slices=n_slices)
+        segptr, idx, e2 = oracle.csr_sliced_from_coo(dst, src, n_dst, n_src, n_slices)
+        for got in (a, b):
+            assert int(got.range_flag) == 0
+            assert np.array_equal(got.segptr.cpu().numpy(), segptr)
+            assert np.array_equal(got.indices.cpu().numpy(), idx) and np.array_equal(got.eid.cpu().numpy(), e2)
+
+
 def test_xcd_sliced_edge_cases(oracle, dev):
     from dream_gnn_amd import ops
 
