@@ -23,7 +23,8 @@ namespace dgmi {
 namespace {
 
 constexpr int64_t kColumnPassMinRows = 32768;  // column passes only when a pass still has >= ~8k waves
-constexpr int kRowsPerGroup = 8;  // <= LPR (row boundaries live one per lane of the group)
+constexpr int kRowsPerGroup = 8;  // < LPR (row boundaries live one per lane of the group)
+constexpr int kTouchAheadBlocks = 24;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -73,9 +74,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
     const float* __restrict__ vals, const float* __restrict__ X, int64_t ldx,
     const float* __restrict__ src_scale, float* __restrict__ planes, int64_t ldp, int64_t n_dst,
     int64_t row_begin, int64_t row_end, int F, int n_slices, const int32_t* __restrict__ eid,
-    const KeepSeg* __restrict__ keep, int n_keep) {
+    const KeepSeg* __restrict__ keep, int n_keep, int pf_blocks, int rows_per_group) {
   constexpr int G = kWave / LPR;
-  constexpr int R = kRowsPerGroup < LPR ? kRowsPerGroup : LPR - 1;
+  const int R = rows_per_group;  // < LPR: a group's row boundaries live one per lane
   constexpr bool WEIGHTED = HAS_VALS || HAS_SS;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
@@ -110,6 +111,34 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
       nxt_w = HAS_VALS ? vals[q] : 1.f;
       if (HAS_SS) nxt_w *= src_scale[KEEP ? nxt_idx & 0x7fffffff : nxt_idx];
     }
+  }
+  // Touch-ahead: the id stream and the boundaries are read once, so a wave's first two loads (boundaries, then ids)
+  // miss every cache and it gathers nothing for two memory latencies of its ~20 us life.  Wave 0 of a block therefore
+  // touches the lines the block pf_blocks further on IN THE SAME SLICE (same XCD, same L2) will start from; nobody waits
+  // for these loads but wave 0's own first gathers (vmcnt is in order).  The ids' position is estimated from this block's
+  // own (exact) position and the slice's average ids per block — a hint, never relied on.
+  int pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pf4 = 0;
+  if (pf_blocks > 0 && wave == 0) {
+    const int32_t* sp_s = segptr + (int64_t)slice * n_dst;
+    const int s_lo = sp_s[row_begin], s_hi = sp_s[row_end];
+    const int64_t nblk = gridDim.x / (unsigned)n_slices;
+    const int per_blk = (int)(((int64_t)(s_hi - s_lo) + nblk - 1) / nblk);
+    const int e_blk = __builtin_amdgcn_readfirstlane(e_begin);  // lane 0: the block's first row
+    const int64_t tgt = (int64_t)e_blk + (int64_t)pf_blocks * per_blk - 32;
+    const int lines = (per_blk >> 5) + 3;  // 32 ids per 128-B line, and the estimate's jitter
+    const int64_t pa = tgt + (int64_t)lane * 32, pb = pa + 64 * 32;
+    if (lane < lines && pa >= s_lo && pa < s_hi) {
+      pf0 = indices[pa];
+      if (HAS_VALS) pf1 = __float_as_int(vals[pa]);
+      if (KEEP) pf1 += eid[pa];
+    }
+    if (lane + 64 < lines && pb >= s_lo && pb < s_hi) {
+      pf2 = indices[pb];
+      if (HAS_VALS) pf3 = __float_as_int(vals[pb]);
+    }
+    const int kRowsPerBlock = kWavesPerBlock * G * R;
+    const int64_t rp = row_begin + (block + pf_blocks) * kRowsPerBlock + (int64_t)lane * 32;
+    if (lane * 32 <= kRowsPerBlock && rp <= row_end) pf4 = sp_s[rp];
   }
   for (int base = e_begin; base < e_end; base += LPR) {
     const int n = min(LPR, e_end - base);
@@ -192,6 +221,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
     if (col_ok) store_plane_row(prow + (int64_t)r * ldp, acc);
     acc = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // the touched words are "used" here (no instruction) so that their loads exist and are waited for last
+  asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3), "v"(pf4));
 }
 
 // Y[row] = dst_scale[row] * (plane_0[row] + plane_1[row] + ...) in slice order; one float4 per
@@ -258,7 +289,14 @@ __global__ __launch_bounds__(256) void reduce_planes_kernel(const float* __restr
 template <int LPR>
 hipError_t launch_sliced(const SlicedArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
   constexpr int G = kWave / LPR;
-  constexpr int R = kRowsPerGroup < LPR ? kRowsPerGroup : LPR - 1;
+  // Rows per lane group.  In the step (cold id stream, touch-ahead on), G edges/s at 4 / 6 / 8 / 12 / 15 rows: half-width
+  // products 31.8 / 31.2 / 30.8 / 28.2 / 27.9, full-width ones 28.4 / 29.5 / 30.1 / 30.2 / 30.3, the step 30.8 / 31.0 / 31.0 /
+  // 30.1 / 29.7.  One value for every width: where a group's run starts decides how its batches of 8 are cut, so a
+  // width-dependent value would make the column passes round differently from the full-width pass (they are bit-identical,
+  // test_xcd_sliced_column_passes).  DGMI_SLICED_ROWS forces a value (tools).
+  const char* rows_env = getenv("DGMI_SLICED_ROWS");
+  const int rows_req = rows_env != nullptr ? atoi(rows_env) : kRowsPerGroup;
+  const int R = rows_req < 1 ? 1 : (rows_req < LPR ? rows_req : LPR - 1);
   const int64_t per_block = (int64_t)kWavesPerBlock * G * R;
   const int64_t blocks = (row_end - row_begin + per_block - 1) / per_block;
   dim3 grid((unsigned)(blocks * a.n_slices), (unsigned)((a.F + 4 * LPR - 1) / (4 * LPR)));
@@ -266,16 +304,23 @@ hipError_t launch_sliced(const SlicedArgs& a, int64_t row_begin, int64_t row_end
   const int key = (a.vals ? 4 : 0) | (a.src_scale ? 2 : 0) | (a.n_keep > 0 ? 1 : 0);
   const bool no_off32 = getenv("DGMI_NO_OFF32") != nullptr;  // A/B switch (tools; read per call so one process can flip it)
   const bool off32 = !no_off32 && (a.n_src * a.ldx + a.F) * 4 < ((int64_t)1 << 32);
+  // Touch-ahead distance in blocks of one slice (see the kernel): an XCD starts ~7 blocks of its slice per us, so 24 blocks
+  // are ~3.5 us of lead — a memory latency, and short enough for the touched lines to still be in its L2.  Step of bench.py
+  // at 0 / 16 / 24 / 32: 2.724 / 2.553 / 2.548 / 2.548 ms.  DGMI_SLICED_PF overrides (tools/cold_ids_probe.py; 0 = off).
+  const char* pf_env = getenv("DGMI_SLICED_PF");
+  const int pf_blocks = pf_env != nullptr ? atoi(pf_env) : kTouchAheadBlocks;
 #define DGMI_LAUNCH(V, S, K)                                                                                    \
   do {                                                                                                          \
     if (off32)                                                                                                  \
       hipLaunchKernelGGL((spmm_sliced_vec4_kernel<LPR, V, S, K, true>), grid, block, 0, s, a.segptr, a.indices,  \
                          a.vals, a.X, a.ldx, a.src_scale, a.planes, a.ldp, a.n_dst, row_begin, row_end,          \
-                         (int)a.F, (int)a.n_slices, a.eid, static_cast<const KeepSeg*>(a.keep), a.n_keep);       \
+                         (int)a.F, (int)a.n_slices, a.eid, static_cast<const KeepSeg*>(a.keep), a.n_keep,       \
+                         pf_blocks, R);                                                                          \
     else                                                                                                        \
       hipLaunchKernelGGL((spmm_sliced_vec4_kernel<LPR, V, S, K, false>), grid, block, 0, s, a.segptr, a.indices, \
                          a.vals, a.X, a.ldx, a.src_scale, a.planes, a.ldp, a.n_dst, row_begin, row_end,          \
-                         (int)a.F, (int)a.n_slices, a.eid, static_cast<const KeepSeg*>(a.keep), a.n_keep);       \
+                         (int)a.F, (int)a.n_slices, a.eid, static_cast<const KeepSeg*>(a.keep), a.n_keep,       \
+                         pf_blocks, R);                                                                          \
   } while (0)
   switch (key) {
     case 0: DGMI_LAUNCH(false, false, false); break;
