@@ -24,7 +24,8 @@ namespace {
 
 constexpr int64_t kColumnPassMinRows = 32768;  // column passes only when a pass still has >= ~8k waves
 constexpr int kRowsPerGroup = 8;  // < LPR (row boundaries live one per lane of the group)
-constexpr int kTouchAheadBlocks = 24;
+constexpr int kTouchLead = 24;   // worker blocks of a slice between a toucher and the blocks it touches for
+constexpr int kTouchGroup = 8;   // worker blocks per toucher block
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -51,7 +52,8 @@ __device__ __forceinline__ void store_plane_row(float* p, const float4& v) {
 // boundaries (held one per lane, fetched with ds_bpermute when crossed).  No bubble between
 // rows, no cross-group reduction.  Within a row the sum is sequential in edge order.
 //
-// grid.x = n_slices * ceil(rows / (4 waves * G groups * kRowsPerGroup)); block b: slice = b % n_slices.
+// grid.x = n_slices * (worker blocks + toucher blocks), worker blocks = ceil(rows / (4 waves * G groups * kRowsPerGroup));
+// block b: slice = b % n_slices.
 // Rows [row_begin, row_end) of every slice; plane row index is relative to row_begin.
 // KEEP: edge dropout on the fly — an edge whose keep(eid[p]) fails (dgmi_keep.h) is flagged in the sign
 // bit of its source id; its gather repeats the group's previous row (an L1 hit — never one fixed row,
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
     const float* __restrict__ vals, const float* __restrict__ X, int64_t ldx,
     const float* __restrict__ src_scale, float* __restrict__ planes, int64_t ldp, int64_t n_dst,
     int64_t row_begin, int64_t row_end, int F, int n_slices, const int32_t* __restrict__ eid,
-    const KeepSeg* __restrict__ keep, int n_keep, int pf_blocks, int rows_per_group) {
+    const KeepSeg* __restrict__ keep, int n_keep, int touch_lead, int rows_per_group, int touch_group) {
   constexpr int G = kWave / LPR;
   const int R = rows_per_group;  // < LPR: a group's row boundaries live one per lane
   constexpr bool WEIGHTED = HAS_VALS || HAS_SS;
@@ -82,7 +84,44 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
   const int wave = threadIdx.x >> 6;
   const int grp = lane / LPR, glane = lane % LPR, gbase = grp * LPR;
   const int slice = (int)(blockIdx.x % (unsigned)n_slices);
-  const int64_t block = blockIdx.x / (unsigned)n_slices;
+  int64_t block = blockIdx.x / (unsigned)n_slices;
+  if (touch_group > 0) {
+    // Touch-ahead.  The id stream and the row boundaries are read once, so a wave's first two loads (boundaries, then
+    // ids — dependent) miss every cache, and it gathers nothing for two memory latencies of its ~20 us life: inside a
+    // training step, where the other products have pushed this one's ids out of the Infinity Cache, that is 10-25 % of the
+    // product.  Every (touch_group + 1)-th block of a slice therefore gathers nothing: it touches the boundaries and the id
+    // lines (one word per 128-B line) of the touch_group worker blocks that start touch_lead worker blocks further on IN THE
+    // SAME SLICE — same XCD, same L2, a few microseconds later — and leaves.  Nobody waits for these loads but the toucher
+    // (vmcnt is in order: a worker that issued them would hold its own first gathers back).  A hint: results never depend on it.
+    const int64_t t = block / (touch_group + 1);
+    if (block % (touch_group + 1) == 0) {
+      __shared__ int range[2];
+      const int32_t* sp_s = segptr + (int64_t)slice * n_dst;
+      const int64_t rows_blk = (int64_t)kWavesPerBlock * G * R;
+      const int64_t r_first = row_begin + (t * touch_group + touch_lead) * rows_blk;
+      if (r_first >= row_end) return;  // block-uniform
+      const int64_t r_last = min(r_first + touch_group * rows_blk, row_end);
+      int keepalive = 0;
+      if (wave == 0) {  // lanes 0 / 1: the id range of those blocks; the others: one word per line of their boundaries
+        const int64_t rp = lane == 0 ? r_first : (lane == 1 ? r_last : r_first + (int64_t)(lane - 1) * 32);
+        if (rp <= r_last) {
+          const int v = sp_s[rp];
+          if (lane < 2) range[lane] = v;
+          keepalive = v;
+        }
+      }
+      __syncthreads();
+      const int e0 = range[0], e1 = range[1];
+      for (int64_t p = (int64_t)e0 + (int64_t)threadIdx.x * 32; p < e1; p += (int64_t)blockDim.x * 32) {
+        keepalive ^= indices[p];
+        if (HAS_VALS) keepalive ^= __float_as_int(vals[p]);
+        if (KEEP) keepalive ^= eid[p];
+      }
+      asm volatile("" ::"v"(keepalive));  // the loads exist, and are waited for, without an instruction
+      return;
+    }
+    block -= t + 1;  // worker blocks are numbered without the touchers
+  }
   const int64_t row0 = row_begin + ((block * kWavesPerBlock + wave) * G + grp) * R;
   if (row0 >= row_end) return;  // whole group idle (lanes of other groups carry on)
   const int nr = (int)(row0 + R <= row_end ? R : row_end - row0);
@@ -111,34 +150,6 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
       nxt_w = HAS_VALS ? vals[q] : 1.f;
       if (HAS_SS) nxt_w *= src_scale[KEEP ? nxt_idx & 0x7fffffff : nxt_idx];
     }
-  }
-  // Touch-ahead: the id stream and the boundaries are read once, so a wave's first two loads (boundaries, then ids)
-  // miss every cache and it gathers nothing for two memory latencies of its ~20 us life.  Wave 0 of a block therefore
-  // touches the lines the block pf_blocks further on IN THE SAME SLICE (same XCD, same L2) will start from; nobody waits
-  // for these loads but wave 0's own first gathers (vmcnt is in order).  The ids' position is estimated from this block's
-  // own (exact) position and the slice's average ids per block — a hint, never relied on.
-  int pf0 = 0, pf1 = 0, pf2 = 0, pf3 = 0, pf4 = 0;
-  if (pf_blocks > 0 && wave == 0) {
-    const int32_t* sp_s = segptr + (int64_t)slice * n_dst;
-    const int s_lo = sp_s[row_begin], s_hi = sp_s[row_end];
-    const int64_t nblk = gridDim.x / (unsigned)n_slices;
-    const int per_blk = (int)(((int64_t)(s_hi - s_lo) + nblk - 1) / nblk);
-    const int e_blk = __builtin_amdgcn_readfirstlane(e_begin);  // lane 0: the block's first row
-    const int64_t tgt = (int64_t)e_blk + (int64_t)pf_blocks * per_blk - 32;
-    const int lines = (per_blk >> 5) + 3;  // 32 ids per 128-B line, and the estimate's jitter
-    const int64_t pa = tgt + (int64_t)lane * 32, pb = pa + 64 * 32;
-    if (lane < lines && pa >= s_lo && pa < s_hi) {
-      pf0 = indices[pa];
-      if (HAS_VALS) pf1 = __float_as_int(vals[pa]);
-      if (KEEP) pf1 += eid[pa];
-    }
-    if (lane + 64 < lines && pb >= s_lo && pb < s_hi) {
-      pf2 = indices[pb];
-      if (HAS_VALS) pf3 = __float_as_int(vals[pb]);
-    }
-    const int kRowsPerBlock = kWavesPerBlock * G * R;
-    const int64_t rp = row_begin + (block + pf_blocks) * kRowsPerBlock + (int64_t)lane * 32;
-    if (lane * 32 <= kRowsPerBlock && rp <= row_end) pf4 = sp_s[rp];
   }
   for (int base = e_begin; base < e_end; base += LPR) {
     const int n = min(LPR, e_end - base);
@@ -221,8 +232,6 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
     if (col_ok) store_plane_row(prow + (int64_t)r * ldp, acc);
     acc = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  // the touched words are "used" here (no instruction) so that their loads exist and are waited for last
-  asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3), "v"(pf4));
 }
 
 // Y[row] = dst_scale[row] * (plane_0[row] + plane_1[row] + ...) in slice order; one float4 per
@@ -299,28 +308,32 @@ hipError_t launch_sliced(const SlicedArgs& a, int64_t row_begin, int64_t row_end
   const int R = rows_req < 1 ? 1 : (rows_req < LPR ? rows_req : LPR - 1);
   const int64_t per_block = (int64_t)kWavesPerBlock * G * R;
   const int64_t blocks = (row_end - row_begin + per_block - 1) / per_block;
-  dim3 grid((unsigned)(blocks * a.n_slices), (unsigned)((a.F + 4 * LPR - 1) / (4 * LPR)));
   dim3 block(kWave * kWavesPerBlock);
   const int key = (a.vals ? 4 : 0) | (a.src_scale ? 2 : 0) | (a.n_keep > 0 ? 1 : 0);
   const bool no_off32 = getenv("DGMI_NO_OFF32") != nullptr;  // A/B switch (tools; read per call so one process can flip it)
   const bool off32 = !no_off32 && (a.n_src * a.ldx + a.F) * 4 < ((int64_t)1 << 32);
-  // Touch-ahead distance in blocks of one slice (see the kernel): an XCD starts ~7 blocks of its slice per us, so 24 blocks
-  // are ~3.5 us of lead — a memory latency, and short enough for the touched lines to still be in its L2.  Step of bench.py
-  // at 0 / 16 / 24 / 32: 2.724 / 2.553 / 2.548 / 2.548 ms.  DGMI_SLICED_PF overrides (tools/cold_ids_probe.py; 0 = off).
+  // Touch-ahead (see the kernel): one toucher per kTouchGroup worker blocks, kTouchLead worker blocks ahead.  An XCD starts
+  // ~7 blocks of its slice per us, so 24 blocks are ~3.5 us of lead — a memory latency, and short enough for the touched
+  // lines to still be in its L2.  Step of bench.py: no touching 2.724 ms; wave 0 of every block touching for the block 16 /
+  // 24 / 32 further on 2.553 / 2.548 / 2.548; toucher blocks, one per 4 / 8 / 16 workers 2.526 / 2.528 / 2.530
+  // (profiles/r03_touch_ahead/).  DGMI_SLICED_PF overrides the lead (tools/cold_ids_probe.py; 0 = no touchers).
   const char* pf_env = getenv("DGMI_SLICED_PF");
-  const int pf_blocks = pf_env != nullptr ? atoi(pf_env) : kTouchAheadBlocks;
+  const int touch_lead = pf_env != nullptr ? atoi(pf_env) : kTouchLead;
+  const int touch_group = touch_lead > 0 ? kTouchGroup : 0;
+  const int64_t touchers = touch_group > 0 ? (blocks + touch_group - 1) / touch_group : 0;
+  dim3 grid((unsigned)((blocks + touchers) * a.n_slices), (unsigned)((a.F + 4 * LPR - 1) / (4 * LPR)));
 #define DGMI_LAUNCH(V, S, K)                                                                                    \
   do {                                                                                                          \
     if (off32)                                                                                                  \
       hipLaunchKernelGGL((spmm_sliced_vec4_kernel<LPR, V, S, K, true>), grid, block, 0, s, a.segptr, a.indices,  \
                          a.vals, a.X, a.ldx, a.src_scale, a.planes, a.ldp, a.n_dst, row_begin, row_end,          \
                          (int)a.F, (int)a.n_slices, a.eid, static_cast<const KeepSeg*>(a.keep), a.n_keep,       \
-                         pf_blocks, R);                                                                          \
+                         touch_lead, R, touch_group);                                                             \
     else                                                                                                        \
       hipLaunchKernelGGL((spmm_sliced_vec4_kernel<LPR, V, S, K, false>), grid, block, 0, s, a.segptr, a.indices, \
                          a.vals, a.X, a.ldx, a.src_scale, a.planes, a.ldp, a.n_dst, row_begin, row_end,          \
                          (int)a.F, (int)a.n_slices, a.eid, static_cast<const KeepSeg*>(a.keep), a.n_keep,       \
-                         pf_blocks, R);                                                                          \
+                         touch_lead, R, touch_group);                                                             \
   } while (0)
   switch (key) {
     case 0: DGMI_LAUNCH(false, false, false); break;
