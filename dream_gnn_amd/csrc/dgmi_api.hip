@@ -170,8 +170,6 @@ DGMI_API int dgmi_spmm_csr_planned_f32(const int32_t* indptr, const int32_t* ind
 }
 
 static int64_t slice_width_for(int64_t n_cols, int32_t n_slices) {
-  const char* env = getenv("DGMI_SLICE_WIDTH");  // EXPERIMENT: narrower leading slices, the last one takes the rest
-  if (env != nullptr && atoll(env) > 0) return atoll(env);
   const int64_t w = (n_cols + n_slices - 1) / n_slices;
   return w > 0 ? w : 1;
 }

@@ -70,29 +70,21 @@ __device__ __forceinline__ float4 ld_row(const float* __restrict__ X, const floa
   return ld4(Xc + (int64_t)idx * ldx);
 }
 
-//
-// TAIL: the launch that ENDS the product when the layout carries one slice more than the planes (see spmm_sliced_f32).
-// Every block, on whatever XCD, gathers from that last slice (all 8 L2s hold it), keeps the partial rows of its lane
-// groups in LDS, and then does what reduce_planes_kernel does for its rows — the n_slices planes of the first launch
-// in slice order, then its own partial, dst_scale, the output epilogue, Y.  The plane stream is HBM-bound and the
-// gather L2-bound: one launch pays for both.
-template <int LPR, bool HAS_VALS, bool HAS_SS, bool KEEP, bool OFF32, bool TAIL>
+template <int LPR, bool HAS_VALS, bool HAS_SS, bool KEEP, bool OFF32>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ indices,
     const float* __restrict__ vals, const float* __restrict__ X, int64_t ldx,
     const float* __restrict__ src_scale, float* __restrict__ planes, int64_t ldp, int64_t n_dst,
     int64_t row_begin, int64_t row_end, int F, int n_slices, const int32_t* __restrict__ eid,
-    const KeepSeg* __restrict__ keep, int n_keep, int touch_lead, int rows_per_group, int touch_group,
-    const float* __restrict__ dst_scale, float* __restrict__ Y, int64_t ldy, Epilogue ep) {
-  extern __shared__ float4 stash[];  // TAIL: [wave][row of the group][lane]
+    const KeepSeg* __restrict__ keep, int n_keep, int touch_lead, int rows_per_group, int touch_group) {
   constexpr int G = kWave / LPR;
   const int R = rows_per_group;  // < LPR: a group's row boundaries live one per lane
   constexpr bool WEIGHTED = HAS_VALS || HAS_SS;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int grp = lane / LPR, glane = lane % LPR, gbase = grp * LPR;
-  const int slice = TAIL ? n_slices : (int)(blockIdx.x % (unsigned)n_slices);
-  int64_t block = TAIL ? (int64_t)blockIdx.x : (int64_t)(blockIdx.x / (unsigned)n_slices);
+  const int slice = (int)(blockIdx.x % (unsigned)n_slices);
+  int64_t block = blockIdx.x / (unsigned)n_slices;
   if (touch_group > 0) {
     // Touch-ahead.  The id stream and the row boundaries are read once, so a wave's first two loads (boundaries, then
     // ids — dependent) miss every cache, and it gathers nothing for two memory latencies of its ~20 us life: inside a
@@ -139,8 +131,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
   const float* Xc = X + col;
   const uint32_t row_bytes = (uint32_t)ldx * 4u, col_bytes = (uint32_t)col * 4u;
   const int32_t* sp = segptr + (int64_t)slice * n_dst + row0;
-  float* prow = planes + ((int64_t)(TAIL ? 0 : slice) * (row_end - row_begin) + (row0 - row_begin)) * ldp + col;
-  float4* const my_stash = stash + (int64_t)wave * R * kWave + lane;
+  float* prow = planes + ((int64_t)slice * (row_end - row_begin) + (row0 - row_begin)) * ldp + col;
 
   const int my_b = sp[glane < nr ? glane : nr];  // lane k holds boundary k (k <= nr)
   const int e_begin = __shfl(my_b, gbase, kWave);
@@ -217,8 +208,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
         const int p = base + j + u;
         if (p < e_end) {  // group-uniform
           while (p >= next_b) {  // row(s) ended before this edge: emit them (empty rows emit zeros)
-            if (TAIL) my_stash[r * kWave] = acc;
-            else if (col_ok) store_plane_row(prow + (int64_t)r * ldp, acc);
+            if (col_ok) store_plane_row(prow + (int64_t)r * ldp, acc);
             acc = make_float4(0.f, 0.f, 0.f, 0.f);
             ++r;
             next_b = __shfl(my_b, gbase + r + 1, kWave);
@@ -239,60 +229,8 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
     }
   }
   for (; r < nr; ++r) {  // the last non-empty row, then any trailing empty rows
-    if (TAIL) my_stash[r * kWave] = acc;
-    else if (col_ok) store_plane_row(prow + (int64_t)r * ldp, acc);
+    if (col_ok) store_plane_row(prow + (int64_t)r * ldp, acc);
     acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  if (TAIL) {
-    // Each lane reads back what it stashed itself: no barrier.  Two rows' plane loads in flight.
-    if (!col_ok) return;
-    constexpr int NP = 8;  // planes of the first launch (the host takes this path for 8 only)
-    const int64_t plane_stride = (row_end - row_begin) * ldp;
-    const int64_t rel0 = row0 - row_begin;
-    float* yrow = Y + rel0 * ldy + col;
-    auto finish = [&](int rr, const float4* v) {
-      float4 t = v[0];
-#pragma unroll
-      for (int sidx = 1; sidx < NP; ++sidx) {
-        t.x += v[sidx].x;
-        t.y += v[sidx].y;
-        t.z += v[sidx].z;
-        t.w += v[sidx].w;
-      }
-      const float4 own = my_stash[rr * kWave];
-      t.x += own.x;
-      t.y += own.y;
-      t.z += own.z;
-      t.w += own.w;
-      if (dst_scale != nullptr) {
-        const float d = dst_scale[rel0 + rr];
-        t.x *= d;
-        t.y *= d;
-        t.z *= d;
-        t.w *= d;
-      }
-      *reinterpret_cast<float4*>(yrow + (int64_t)rr * ldy) = epilogue4(ep, t, rel0 + rr, col);
-    };
-    auto fetch = [&](int rr, float4* v) {
-#pragma unroll
-      for (int sidx = 0; sidx < NP; ++sidx) {
-        const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(prow + (int64_t)rr * ldp + sidx * plane_stride));
-        v[sidx] = make_float4(t.x, t.y, t.z, t.w);
-      }
-    };
-    int rr = 0;
-    for (; rr + 2 <= nr; rr += 2) {
-      float4 va[NP], vb[NP];
-      fetch(rr, va);
-      fetch(rr + 1, vb);
-      finish(rr, va);
-      finish(rr + 1, vb);
-    }
-    if (rr < nr) {
-      float4 va[NP];
-      fetch(rr, va);
-      finish(rr, va);
-    }
   }
 }
 
@@ -357,18 +295,15 @@ __global__ __launch_bounds__(256) void reduce_planes_kernel(const float* __restr
   }
 }
 
-// n_main: slices dealt over the XCDs by this launch (tail = false), or the index of the one slice the TAIL launch
-// gathers from (tail = true; its blocks also add the n_main planes and write Y).
 template <int LPR>
-hipError_t launch_sliced(const SlicedArgs& a, int64_t row_begin, int64_t row_end, int n_main, bool tail, const float* ds,
-                         float* y, const Epilogue& ep, hipStream_t s) {
+hipError_t launch_sliced(const SlicedArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
   constexpr int G = kWave / LPR;
   // Rows per lane group.  In the step (cold id stream, touch-ahead on), G edges/s at 4 / 6 / 8 / 12 / 15 rows: half-width
   // products 31.8 / 31.2 / 30.8 / 28.2 / 27.9, full-width ones 28.4 / 29.5 / 30.1 / 30.2 / 30.3, the step 30.8 / 31.0 / 31.0 /
   // 30.1 / 29.7.  One value for every width: where a group's run starts decides how its batches of 8 are cut, so a
   // width-dependent value would make the column passes round differently from the full-width pass (they are bit-identical,
   // test_xcd_sliced_column_passes).  DGMI_SLICED_ROWS forces a value (tools).
-  const char* rows_env = getenv(tail ? "DGMI_TAIL_ROWS" : "DGMI_SLICED_ROWS");
+  const char* rows_env = getenv("DGMI_SLICED_ROWS");
   const int rows_req = rows_env != nullptr ? atoi(rows_env) : kRowsPerGroup;
   const int R = rows_req < 1 ? 1 : (rows_req < LPR ? rows_req : LPR - 1);
   const int64_t per_block = (int64_t)kWavesPerBlock * G * R;
@@ -382,26 +317,23 @@ hipError_t launch_sliced(const SlicedArgs& a, int64_t row_begin, int64_t row_end
   // lines to still be in its L2.  Step of bench.py: no touching 2.724 ms; wave 0 of every block touching for the block 16 /
   // 24 / 32 further on 2.553 / 2.548 / 2.548; toucher blocks, one per 4 / 8 / 16 workers 2.526 / 2.528 / 2.530
   // (profiles/r03_touch_ahead/).  DGMI_SLICED_PF overrides the lead (tools/cold_ids_probe.py; 0 = no touchers).
-  const char* pf_env = getenv(tail ? "DGMI_TAIL_PF" : "DGMI_SLICED_PF");
-  const int touch_lead = pf_env != nullptr ? atoi(pf_env) : (tail ? 8 * kTouchLead : kTouchLead);
+  const char* pf_env = getenv("DGMI_SLICED_PF");
+  const int touch_lead = pf_env != nullptr ? atoi(pf_env) : kTouchLead;
   const int touch_group = touch_lead > 0 ? kTouchGroup : 0;
   const int64_t touchers = touch_group > 0 ? (blocks + touch_group - 1) / touch_group : 0;
-  dim3 grid((unsigned)((blocks + touchers) * (tail ? 1 : n_main)), (unsigned)((a.F + 4 * LPR - 1) / (4 * LPR)));
-  const size_t lds = tail ? (size_t)kWavesPerBlock * R * kWave * sizeof(float4) : 0;
-#define DGMI_LAUNCH4(V, S, K, O, T)                                                                              \
-  hipLaunchKernelGGL((spmm_sliced_vec4_kernel<LPR, V, S, K, O, T>), grid, block, lds, s, a.segptr, a.indices,    \
-                     a.vals, a.X, a.ldx, a.src_scale, a.planes, a.ldp, a.n_dst, row_begin, row_end, (int)a.F,   \
-                     n_main, a.eid, static_cast<const KeepSeg*>(a.keep), a.n_keep, touch_lead, R, touch_group,  \
-                     ds, y, a.ldy, ep)
-#define DGMI_LAUNCH(V, S, K)                          \
-  do {                                                \
-    if (off32) {                                      \
-      if (tail) DGMI_LAUNCH4(V, S, K, true, true);    \
-      else DGMI_LAUNCH4(V, S, K, true, false);        \
-    } else {                                          \
-      if (tail) DGMI_LAUNCH4(V, S, K, false, true);   \
-      else DGMI_LAUNCH4(V, S, K, false, false);       \
-    }                                                 \
+  dim3 grid((unsigned)((blocks + touchers) * a.n_slices), (unsigned)((a.F + 4 * LPR - 1) / (4 * LPR)));
+#define DGMI_LAUNCH(V, S, K)                                                                                    \
+  do {                                                                                                          \
+    if (off32)                                                                                                  \
+      hipLaunchKernelGGL((spmm_sliced_vec4_kernel<LPR, V, S, K, true>), grid, block, 0, s, a.segptr, a.indices,  \
+                         a.vals, a.X, a.ldx, a.src_scale, a.planes, a.ldp, a.n_dst, row_begin, row_end,          \
+                         (int)a.F, (int)a.n_slices, a.eid, static_cast<const KeepSeg*>(a.keep), a.n_keep,       \
+                         touch_lead, R, touch_group);                                                             \
+    else                                                                                                        \
+      hipLaunchKernelGGL((spmm_sliced_vec4_kernel<LPR, V, S, K, false>), grid, block, 0, s, a.segptr, a.indices, \
+                         a.vals, a.X, a.ldx, a.src_scale, a.planes, a.ldp, a.n_dst, row_begin, row_end,          \
+                         (int)a.F, (int)a.n_slices, a.eid, static_cast<const KeepSeg*>(a.keep), a.n_keep,       \
+                         touch_lead, R, touch_group);                                                             \
   } while (0)
   switch (key) {
     case 0: DGMI_LAUNCH(false, false, false); break;
@@ -414,7 +346,6 @@ hipError_t launch_sliced(const SlicedArgs& a, int64_t row_begin, int64_t row_end
     default: DGMI_LAUNCH(true, true, true); break;
   }
 #undef DGMI_LAUNCH
-#undef DGMI_LAUNCH4
   return hipGetLastError();
 }
 
@@ -427,10 +358,6 @@ hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s) {
   // written and read back while still resident in the 256 MiB Infinity Cache, and the same
   // plane buffer is reused by every chunk.
   const int64_t chunk = a.chunk_rows > 0 ? a.chunk_rows : a.n_dst;
-  // EXPERIMENT (DGMI_SLICED_TAIL=1, 9-slice layouts): slices 0..7 one per XCD into 8 planes, slice 8 by the launch that
-  // also reduces the planes.
-  const bool tail = a.n_slices == 9 && getenv("DGMI_SLICED_TAIL") != nullptr;
-  const int n_main = tail ? 8 : (int)a.n_slices;
   for (int64_t r0 = 0; r0 < a.n_dst; r0 += chunk) {
     const int64_t r1 = r0 + chunk < a.n_dst ? r0 + chunk : a.n_dst;
     hipError_t err;
@@ -452,45 +379,26 @@ hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s) {
     // DGMI_SLICED_LPR forces a width (tools).
     const char* lpr_env = getenv("DGMI_SLICED_LPR");  // read per call: tools flip it inside one process
     const int forced_lpr = lpr_env != nullptr ? atoi(lpr_env) : 0;
-    const char* w_env = getenv("DGMI_SLICE_WIDTH");  // EXPERIMENT: the width the layout was built with
-    const int64_t main_rows = w_env != nullptr && atoll(w_env) > 0 ? atoll(w_env) : (a.n_src + a.n_slices - 1) / a.n_slices;
-    const int64_t tail_rows = tail ? a.n_src - n_main * main_rows : 0;
     int lpr = pick_lpr(a.F);
-    int lpr_tail = lpr;
     if (lpr >= 32 && !a.full_width && a.n_keep == 0 && a.n_dst >= kColumnPassMinRows) {
       const int64_t width = 16 * (int64_t)lpr < 4 * a.F ? 16 * (int64_t)lpr : 4 * a.F;
-      if (main_rows * width > (4 << 20)) lpr /= 2;
-    }
-    if (tail && !a.full_width && a.n_keep == 0) {
-      while (lpr_tail > 8 && tail_rows * 16 * lpr_tail > (4 << 20)) lpr_tail /= 2;
+      const int64_t slice_bytes = (a.n_src + a.n_slices - 1) / a.n_slices * width;
+      if (slice_bytes > (4 << 20)) lpr /= 2;
     }
     if (forced_lpr == 8 || forced_lpr == 16 || forced_lpr == 32 || forced_lpr == 64) lpr = forced_lpr;
-    const char* tl_env = getenv("DGMI_TAIL_LPR");
-    const int forced_tl = tl_env != nullptr ? atoi(tl_env) : 0;
-    if (forced_tl == 8 || forced_tl == 16 || forced_tl == 32 || forced_tl == 64) lpr_tail = forced_tl;
+    switch (lpr) {
+      case 8: err = launch_sliced<8>(a, r0, r1, s); break;
+      case 16: err = launch_sliced<16>(a, r0, r1, s); break;
+      case 32: err = launch_sliced<32>(a, r0, r1, s); break;
+      default: err = launch_sliced<64>(a, r0, r1, s); break;
+    }
+    if (err != hipSuccess) return err;
+    int64_t blocks = ((r1 - r0) * F4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
     const float* ds = a.dst_scale ? a.dst_scale + r0 : nullptr;
     float* y = a.Y + r0 * a.ldy;
     Epilogue ep = a.ep;  // rows of this chunk start at r0
     if (ep.mask != nullptr) ep.mask += r0 * ep.ldm;
-    switch (lpr) {
-      case 8: err = launch_sliced<8>(a, r0, r1, n_main, false, ds, y, ep, s); break;
-      case 16: err = launch_sliced<16>(a, r0, r1, n_main, false, ds, y, ep, s); break;
-      case 32: err = launch_sliced<32>(a, r0, r1, n_main, false, ds, y, ep, s); break;
-      default: err = launch_sliced<64>(a, r0, r1, n_main, false, ds, y, ep, s); break;
-    }
-    if (err != hipSuccess) return err;
-    if (tail) {  // the TAIL launch adds the planes and writes Y
-      switch (lpr_tail) {
-        case 8: err = launch_sliced<8>(a, r0, r1, n_main, true, ds, y, ep, s); break;
-        case 16: err = launch_sliced<16>(a, r0, r1, n_main, true, ds, y, ep, s); break;
-        case 32: err = launch_sliced<32>(a, r0, r1, n_main, true, ds, y, ep, s); break;
-        default: err = launch_sliced<64>(a, r0, r1, n_main, true, ds, y, ep, s); break;
-      }
-      if (err != hipSuccess) return err;
-      continue;
-    }
-    int64_t blocks = ((r1 - r0) * F4 + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
 #define DGMI_REDUCE(D, S)                                                                               \
   hipLaunchKernelGGL((reduce_planes_kernel<D, S>), dim3((unsigned)blocks), dim3(256), 0, s, a.planes, a.ldp, \
                      r1 - r0, F4, (int)a.n_slices, ds, y, a.ldy, ep)

@@ -185,7 +185,7 @@ class SlicedCSR:
     """Source-sliced CSR for the XCD-local SpMM (``dgmi_csr_sliced_from_coo_i32``): edges sorted
     by (slice(src), row); ``segptr`` has ``n_slices * n_dst + 1`` entries."""
 
-    N_SLICES = int(os.environ.get("DGMI_N_SLICES", "8"))  # one slice of X per XCD (EXPERIMENT: 9 = 8 + tail)
+    N_SLICES = 8  # one slice of X per XCD
 
     def __init__(self, dst, src, n_dst, n_src, vals=None, n_slices: int = N_SLICES):
         _require_device(dst, src, vals)
