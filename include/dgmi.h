@@ -287,7 +287,7 @@ DGMI_API int dgmi_rank_add_f32(float* G, int64_t ldg, const float* coef, int64_t
  * (D3) Edge dropout selection: a uniformly random subset of exactly `keep` of E edges — what
  * `perm = randperm(E); keep = perm[:num_keep]` (augmentation.py:48-52, 114-118) selects,
  * without materialising the permutation: per-edge keys (hash32(seed, e), e) and a SELECTION of the
- * keep-th smallest key (lists below 2^20 edges: a radix select by one workgroup; longer lists: two
+ * keep-th smallest key (lists below 2^16 edges: a radix select by one workgroup; longer lists: two
  * passes over a window of the hash space around keep / E * 2^32, exact in every case).
  * Deterministic in (seed, E, keep).  workspace: dgmi_random_subset_workspace_bytes() bytes.
  * 0 <= keep <= E.
