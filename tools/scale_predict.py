@@ -46,6 +46,6 @@ for world in worlds:
         print(json.dumps(entry), flush=True)
         del ops
         torch.cuda.empty_cache()
-with open(os.path.join(ROOT, "gpurun_out", "r03_scale_prediction.json")  # copied to profiles/ by hand, "w") as f:
+with open(os.path.join(ROOT, "gpurun_out", "r03_scale_prediction.json"), "w") as f:  # copied to profiles/ by hand
     json.dump({"gpu": torch.cuda.get_device_name(0), "model": S.predict_step_seconds.__doc__, "link_GBps": S.XGMI_LINK_GBS,
                "links": S.XGMI_LINKS, "rows": rows}, f, indent=1)
