@@ -374,3 +374,33 @@ def test_random_subset_selection_is_exact_and_uniformish(oracle):
     assert oracle.random_subset_mask(E, 0, 1).sum() == 0 and oracle.random_subset_mask(E, E, 1).sum() == E
     freq = sum(oracle.random_subset_mask(400, 100, s) for s in range(300)) / 300.0
     assert abs(freq.mean() - 0.25) < 1e-9 and freq.min() > 0.12 and freq.max() < 0.40
+
+
+def test_decoder_edge_linear_split_k_gradients_equal_the_plain_linear():
+    """model._EdgeLinear: the decoder's Linear layers over the edge list with the weight gradient summed chunk by
+    chunk (K = number of train pairs) — same forward, same gradients as nn.Linear up to fp32 summation order; the
+    number of rows is deliberately not a multiple of the chunk."""
+    from dream_gnn_amd import model as M
+
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(24, 10)
+    x = torch.randn(3 * M._EdgeLinear.CHUNK + 517, 24, requires_grad=True)
+    w = torch.randn(x.shape[0], 10)
+    y_ref = lin(x)
+    (y_ref * w).sum().backward()
+    ref = (x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x.grad = None
+    lin.zero_grad()
+    y = M._EdgeLinear.apply(x, lin.weight, lin.bias)
+    (y * w).sum().backward()
+    assert torch.equal(y, y_ref)
+    assert torch.equal(x.grad, ref[0])
+    for got, want in ((lin.weight.grad, ref[1]), (lin.bias.grad, ref[2])):
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    # no bias (lin3-style single output), and the dispatcher's size / device gate
+    lin1 = torch.nn.Linear(24, 1, bias=False)
+    x2 = x.detach().clone().requires_grad_(True)
+    M._EdgeLinear.apply(x2, lin1.weight, None).sum().backward()
+    want = x.detach().sum(0, keepdim=True)
+    assert float((lin1.weight.grad - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert M._edge_linear(lin, x[:8]).shape == (8, 10)  # CPU / short inputs take nn.Linear itself
