@@ -391,6 +391,61 @@ def variants(torch, dev, ops):
     return out
 
 
+def model_steps(torch, dev):
+    """Context, not the judged metric: the whole training iteration of train.py:249-300 (per-step edge dropout +
+    feature noise, 3 GCMC layers + FGCN + attention + decoder, loss, backward, clip, Adam) on the dataset-shaped
+    configs 2 / 3 — eager (`harness.train_step`) and recorded once as a HIP graph (`harness.CapturedTrainStep`: the
+    subsets' seeds are drawn on the device, so nothing in the step needs the host).  ms per step by the wall clock."""
+    import types
+
+    from dream_gnn_amd import graph as G, harness as H, model as M, synth
+
+    out = {}
+    for cfg, blocks, width in (("cfg2 lrssl-shape", [synth.DATASET_SHAPES["lrssl"]], 128),
+                               ("cfg3 C+G merged", [synth.DATASET_SHAPES["Cdataset"], synth.DATASET_SHAPES["Gdataset"]], 256)):
+        try:
+            drug, dis, labels, nd, ns = synth.dataset_shaped_pairs(blocks)
+            batch = {"enc_graph": G.build_enc_graph(drug, dis, labels, nd, ns, device=dev).int(),
+                     "dec_graph": G.build_dec_graph(drug, dis, nd, ns, device=dev).int()}
+            for key, n, seed in (("drug", nd, 1), ("disease", ns, 2)):
+                batch[key + "_sim_feat"] = torch.rand(n, n, device=dev)
+                batch[key + "_feat"] = torch.nn.functional.normalize(torch.randn(n, 768, device=dev))
+                for gname, s2 in ((key + "_graph", 0), (key + "_feature_graph", 10)):
+                    r, c, v = synth.knn_sim_graph(n, 4, seed + s2, dev)
+                    batch[gname] = torch.sparse_coo_tensor(torch.stack([r.long(), c.long()]), v, (n, n))
+            args = types.SimpleNamespace(rating_vals=[0, 1], src_in_units=768, dst_in_units=768, gcn_agg_units=1024,
+                                         gcn_out_units=width, dropout=0.3, gcn_agg_accum="sum", model_activation="leaky",
+                                         share_param=True, device=None, layers=3, fdim_drug=nd, fdim_disease=ns,
+                                         nhid1=768, nhid2=width, attention_dropout=0.5)
+            y = labels.to(dev).float()
+
+            def wall(fn, n=20, warm=3):
+                for _ in range(warm):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e3
+
+            torch.manual_seed(0)
+            net = M.Net(args).to(dev)
+            opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-5)
+            eager = wall(lambda: H.train_step(net, opt, batch, y))
+            torch.manual_seed(0)
+            net = M.Net(args).to(dev)
+            opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-5, capturable=True)
+            step = H.CapturedTrainStep(net, opt, batch, y)
+            out[cfg] = {"train_pairs": int(drug.numel()), "nodes": "%dx%d" % (nd, ns), "width": width,
+                        "training_step_eager_ms": round(eager, 3), "training_step_hip_graph_replay_ms": round(wall(step), 3)}
+            del step, net, opt, batch
+            torch.cuda.empty_cache()
+        except Exception as exc:  # noqa: BLE001 - context numbers must never cost the bench its line
+            out[cfg] = {"error": repr(exc)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -641,6 +696,7 @@ def main():
             out["edge_scaled" if args.scale == "nodes" else "node_scaled"] = other
         if world == 1 and not args.no_variants:
             out["variants"] = variants(torch, dev, ops)
+            out["model_steps"] = model_steps(torch, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(torch, ops)
         print(json.dumps(out), flush=True)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgmi.so")
 TORCH_LIB_PATH = os.path.join(_HERE, "libdgmi_torch.so")  # the dreamgnn_mi::* dispatcher ops over the C ABI
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 # name -> (restype, argtypes); mirrors include/dgmi.h one to one.
 _vp = ctypes.c_void_p
@@ -58,6 +58,7 @@ SIGNATURES = {
     "dgmi_random_subset_select": (ctypes.c_int, [_i64, _i64, ctypes.c_uint64, ctypes.c_uint32, _vp, _vp, ctypes.c_size_t,
                                                  _vp]),
     "dgmi_random_subset_select_batch": (ctypes.c_int, [ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "dgmi_random_subset_select_batch_dseed": (ctypes.c_int, [ctypes.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "dgmi_keep_mask_f32": (ctypes.c_int, [_vp, ctypes.c_int32, _i64, _vp, _vp]),
     "dgmi_scale_rows_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "dgmi_weighted_colsum_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, ctypes.c_int32, _vp, _i64, _vp]),

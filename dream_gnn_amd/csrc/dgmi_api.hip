@@ -367,6 +367,23 @@ DGMI_API int dgmi_random_subset_select_batch(int32_t n, const int64_t* E, const 
   return from_hip(dgmi::random_subset_select_batch(n, E, keep, seed, e_offset, descs, workspace, as_stream(stream)));
 }
 
+DGMI_API int dgmi_random_subset_select_batch_dseed(int32_t n, const int64_t* E, const int64_t* keep, const uint64_t* seed_dev,
+                                                  const uint32_t* e_offset, uint32_t* descs, void* workspace,
+                                                  size_t workspace_bytes, dgmi_stream_t stream) {
+  if (n < 0 || n > dgmi::kMaxKeepSegs) return DGMI_ERR_INVALID_ARG;
+  if (n == 0) return DGMI_OK;
+  if (E == nullptr || keep == nullptr || seed_dev == nullptr || descs == nullptr || workspace == nullptr)
+    return DGMI_ERR_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(seed_dev) & 7) return DGMI_ERR_INVALID_ARG;
+  for (int i = 0; i < n; ++i) {
+    if (E[i] < 0 || keep[i] < 0 || keep[i] > E[i]) return DGMI_ERR_INVALID_ARG;
+    if (E[i] > INT32_MAX || (uint64_t)(e_offset ? e_offset[i] : 0u) + (uint64_t)E[i] > (uint64_t)INT32_MAX)
+      return DGMI_ERR_TOO_LARGE;
+  }
+  if (workspace_bytes < dgmi::random_subset_workspace_bytes()) return DGMI_ERR_WORKSPACE;
+  return from_hip(dgmi::random_subset_select_batch(n, E, keep, nullptr, e_offset, descs, workspace, as_stream(stream), seed_dev));
+}
+
 DGMI_API int dgmi_keep_mask_f32(const uint32_t* keep, int32_t n_keep, int64_t E, float* mask, dgmi_stream_t stream) {
   if (E < 0 || n_keep < 0 || n_keep > dgmi::kMaxKeepSegs || (n_keep > 0 && keep == nullptr)) return DGMI_ERR_INVALID_ARG;
   if (E > INT32_MAX) return DGMI_ERR_TOO_LARGE;

@@ -179,8 +179,10 @@ size_t random_subset_workspace_bytes();
 hipError_t random_subset_select(int64_t E, int64_t keep, uint64_t seed, uint32_t e_offset, void* seg_out,
                                 void* workspace, hipStream_t s);
 // the same for up to 8 edge lists in one series of launches (host arrays of length n; descs: n x 8 words)
+// seed_dev != NULL: n seeds in DEVICE memory, read by the kernels (seed may be NULL then)
 hipError_t random_subset_select_batch(int n, const int64_t* E, const int64_t* keep, const uint64_t* seed,
-                                      const uint32_t* e_offset, void* descs, void* workspace, hipStream_t s);
+                                      const uint32_t* e_offset, void* descs, void* workspace, hipStream_t s,
+                                      const uint64_t* seed_dev = nullptr);
 // mask[e] = keep(e) under `n_seg` descriptions, e in [0, E)
 hipError_t keep_mask_f32(const void* table, int n_seg, int64_t E, float* mask, hipStream_t s);
 hipError_t random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask, void* workspace,

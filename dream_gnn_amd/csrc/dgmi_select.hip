@@ -60,10 +60,16 @@ struct BatchParams {
   int64_t E[kMaxKeepSegs];
   int64_t keep[kMaxKeepSegs];
   uint64_t seed[kMaxKeepSegs];
+  const uint64_t* seed_dev;  // not NULL: the seeds are read from device memory (seed[] unused) — a captured HIP graph
+                             // then draws a new subset on every replay without a host value baked into its launches
   uint32_t e_offset[kMaxKeepSegs];
   int64_t window_min;  // lists of at least this many edges take the window passes (kWindowMinE; DGMI_SELECT_WINDOW_MIN for A/B)
   int narrow;  // tests only (DGMI_SELECT_NARROW_WINDOW=1): a window of ~2 edges, so that it misses and the take-over path runs
 };
+
+__device__ __forceinline__ uint64_t seed_of(const BatchParams& p, int i) {
+  return p.seed_dev != nullptr ? p.seed_dev[i] : p.seed[i];
+}
 
 __device__ __forceinline__ void write_desc(KeepSeg* out, int64_t E, uint64_t seed, uint32_t e_offset, uint32_t thr,
                                            int32_t tie_cut) {
@@ -154,10 +160,10 @@ __global__ __launch_bounds__(kSelectThreads) void select_or_init_kernel(BatchPar
   if (E < p.window_min || keep <= 0 || keep >= E) {
     if (threadIdx.x == 0) st->mode = kDone;
     if (keep <= 0) {  // nothing kept: what the radix select arrives at for rank 0, without the passes
-      if (threadIdx.x == 0) write_desc(descs + i, E, p.seed[i], p.e_offset[i], 0u, -1);
+      if (threadIdx.x == 0) write_desc(descs + i, E, seed_of(p, i), p.e_offset[i], 0u, -1);
       return;
     }
-    block_select(E, keep, p.seed[i], p.e_offset[i], descs + i);
+    block_select(E, keep, seed_of(p, i), p.e_offset[i], descs + i);
     return;
   }
   for (int b = threadIdx.x; b < kBins; b += kSelectThreads) st->hist[b] = 0;
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(kBlock) void window_hist_kernel(BatchParams p, Sele
   SelectState* st = states + blockIdx.y;
   if (st->mode != kWindow) return;
   const int64_t E = p.E[blockIdx.y];
-  const uint64_t seed = p.seed[blockIdx.y];
+  const uint64_t seed = seed_of(p, blockIdx.y);
   const uint32_t lo = st->lo, binw = st->binw;
   const uint64_t hi = (uint64_t)lo + (uint64_t)binw * kBins;  // exclusive
   unsigned long long below = 0;
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(kBlock) void window_collect_kernel(BatchParams p, S
   SelectState* st = states + blockIdx.y;
   if (st->mode != kWindow) return;
   const int64_t E = p.E[blockIdx.y];
-  const uint64_t seed = p.seed[blockIdx.y];
+  const uint64_t seed = seed_of(p, blockIdx.y);
   const uint32_t blo = st->bin_lo, bhi = st->bin_hi;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += stride) {
@@ -271,10 +277,10 @@ __global__ __launch_bounds__(kSelectThreads) void window_finalize_kernel(BatchPa
       st->coll[j] = v;
     }
     const uint2 key = st->coll[st->remaining - 1];  // 1 <= remaining <= n by the bin's count
-    write_desc(descs + i, p.E[i], p.seed[i], p.e_offset[i], key.x, (int32_t)key.y);
+    write_desc(descs + i, p.E[i], seed_of(p, i), p.e_offset[i], key.x, (int32_t)key.y);
     return;
   }
-  block_select(p.E[i], p.keep[i], p.seed[i], p.e_offset[i], descs + i);
+  block_select(p.E[i], p.keep[i], seed_of(p, i), p.e_offset[i], descs + i);
 }
 
 __global__ __launch_bounds__(kBlock) void keep_mask_kernel(const KeepSeg* __restrict__ tab, int n_seg, int64_t E,
@@ -296,7 +302,8 @@ inline unsigned grid_for(int64_t n) {
 size_t random_subset_workspace_bytes() { return sizeof(SelectState) * kMaxKeepSegs + sizeof(KeepSeg); }
 
 hipError_t random_subset_select_batch(int n, const int64_t* E, const int64_t* keep, const uint64_t* seed,
-                                      const uint32_t* e_offset, void* descs, void* workspace, hipStream_t s) {
+                                      const uint32_t* e_offset, void* descs, void* workspace, hipStream_t s,
+                                      const uint64_t* seed_dev) {
   if (n <= 0) return hipSuccess;
   BatchParams p = {};
   const char* wmin = getenv("DGMI_SELECT_WINDOW_MIN");
@@ -305,10 +312,11 @@ hipError_t random_subset_select_batch(int n, const int64_t* E, const int64_t* ke
   for (int i = 0; i < n; ++i) {
     p.E[i] = E[i];
     p.keep[i] = keep[i];
-    p.seed[i] = seed[i];
+    p.seed[i] = seed != nullptr ? seed[i] : 0;
     p.e_offset[i] = e_offset ? e_offset[i] : 0u;
     if (E[i] >= p.window_min && keep[i] > 0 && keep[i] < E[i] && E[i] > e_max) e_max = E[i];
   }
+  p.seed_dev = seed_dev;
   const char* narrow = getenv("DGMI_SELECT_NARROW_WINDOW");
   p.narrow = narrow != nullptr && narrow[0] == '1';
   SelectState* st = static_cast<SelectState*>(workspace);
@@ -327,7 +335,7 @@ hipError_t random_subset_select_batch(int n, const int64_t* E, const int64_t* ke
 
 hipError_t random_subset_select(int64_t E, int64_t keep, uint64_t seed, uint32_t e_offset, void* seg_out,
                                 void* workspace, hipStream_t s) {
-  return random_subset_select_batch(1, &E, &keep, &seed, &e_offset, seg_out, workspace, s);
+  return random_subset_select_batch(1, &E, &keep, &seed, &e_offset, seg_out, workspace, s, nullptr);
 }
 
 hipError_t keep_mask_f32(const void* table, int n_seg, int64_t E, float* mask, hipStream_t s) {

@@ -453,6 +453,28 @@ Tensor random_subset_select_batch(const Tensor& like, at::IntArrayRef E, at::Int
   return descs;
 }
 
+// the same with the seeds in a device tensor (int64, n entries): nothing host-side goes into the launches but the
+// list lengths, so the call can sit inside a captured HIP graph and still select new subsets on every replay
+Tensor random_subset_select_batch_dseed(const Tensor& seeds, at::IntArrayRef E, at::IntArrayRef keep, at::IntArrayRef e_offset) {
+  check_dev(seeds, "seeds");
+  const int64_t n = (int64_t)E.size();
+  TORCH_CHECK(n >= 1 && n <= 8 && (int64_t)keep.size() == n && (e_offset.empty() || (int64_t)e_offset.size() == n),
+              "random_subset_select_batch_dseed: 1..8 subsets, E / keep (/ e_offset) of equal length");
+  TORCH_CHECK(seeds.scalar_type() == at::kLong && seeds.is_contiguous() && seeds.numel() == n,
+              "seeds must be a contiguous int64 tensor with one entry per subset");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(seeds.device());
+  Tensor descs = at::empty({n, 8}, seeds.options().dtype(at::kInt));
+  const size_t nbytes = dgmi_random_subset_workspace_bytes();
+  Tensor ws = at::empty({(int64_t)nbytes}, seeds.options().dtype(at::kByte));
+  uint32_t offs[8];
+  for (int64_t i = 0; i < n; ++i) offs[i] = e_offset.empty() ? 0u : (uint32_t)e_offset[i];
+  check_status(dgmi_random_subset_select_batch_dseed((int32_t)n, E.data(), keep.data(),
+                                                     reinterpret_cast<const uint64_t*>(seeds.data_ptr<int64_t>()), offs,
+                                                     reinterpret_cast<uint32_t*>(descs.data_ptr<int32_t>()), ws.data_ptr(), nbytes,
+                                                     stream_of(seeds)), "dgmi_random_subset_select_batch_dseed");
+  return descs;
+}
+
 Tensor keep_mask(const Tensor& keep, int64_t E) {
   check_dev(keep, "keep");
   TORCH_CHECK(keep.scalar_type() == at::kInt && keep.is_contiguous() && keep.dim() == 2 && keep.size(1) == 8 && keep.size(0) <= 8,
@@ -566,6 +588,7 @@ TORCH_LIBRARY(dreamgnn_mi, m) {
   m.def("gather_add_raw(Tensor src, Tensor dst, Tensor A, Tensor B, Tensor? bias) -> Tensor");
   m.def("random_subset_select(Tensor like, int E, int keep, int seed, int e_offset=0) -> Tensor");
   m.def("random_subset_select_batch(Tensor like, int[] E, int[] keep, int[] seed, int[] e_offset) -> Tensor");
+  m.def("random_subset_select_batch_dseed(Tensor seeds, int[] E, int[] keep, int[] e_offset) -> Tensor");
   m.def("keep_mask(Tensor keep, int E) -> Tensor");
 }
 
@@ -590,6 +613,7 @@ TORCH_LIBRARY_IMPL(dreamgnn_mi, CUDA, m) {
   m.impl("gather_add_raw", gather_add_raw);
   m.impl("random_subset_select", random_subset_select);
   m.impl("random_subset_select_batch", random_subset_select_batch);
+  m.impl("random_subset_select_batch_dseed", random_subset_select_batch_dseed);
   m.impl("keep_mask", keep_mask);
 }
 

@@ -583,6 +583,14 @@ def _draw_seed(generator: Optional[torch.Generator]) -> Optional[int]:
     return int(torch.randint(0, 2 ** 62, (1,), generator=generator).item())
 
 
+def _draw_seeds_on_device(n: int, device, generator: Optional[torch.Generator]) -> torch.Tensor:
+    """``n`` 62-bit seeds drawn ON the device (torch's device RNG, or the device generator handed in): nothing
+    synchronises and no host value is involved — the form a captured HIP graph needs (``selection="select_device"``).
+    The subsets are as uniform as with a host-drawn seed; the RNG stream consumed is the device's, not the CPU's."""
+    gen = generator if generator is not None and generator.device.type != "cpu" else None
+    return torch.randint(0, 2 ** 62, (n,), dtype=torch.int64, device=device, generator=gen)
+
+
 def _select_kept(E: int, keep: int, device, generator, selection: Optional[str]):
     """(keep_idx or None, desc or None) for a uniformly random subset of exactly ``keep`` edges.
 
@@ -595,6 +603,8 @@ def _select_kept(E: int, keep: int, device, generator, selection: Optional[str])
     (augmentation.py:51-52), same RNG consumption as the reference."""
     if selection is None:
         selection = "select" if torch.device(device).type == "cuda" else "randperm"
+    if selection == "select_device":
+        return None, ops.random_subset_select_batch([E], [keep], _draw_seeds_on_device(1, device, generator), device)[0]
     if selection == "select":
         seed = _draw_seed(generator)
         if seed is not None:
@@ -635,6 +645,10 @@ def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
             continue
         keep = max(1, int(E * (1 - dropout_rate)))
         sel = selection or ("select" if rel.device.type == "cuda" else "randperm")
+        if sel == "select_device":  # seeds drawn on the device, all at once, below
+            out._rels[can] = None
+            pending.append((can, rel, keep, None))
+            continue
         seed = _draw_seed(generator) if sel == "select" else None  # one draw per edge type, in canonical order
         if seed is not None:
             out._rels[can] = None  # keeps the canonical position
@@ -643,8 +657,11 @@ def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
             keep_idx = torch.randperm(E, device=rel.device, generator=generator)[:keep]
             out._rels[can] = DroppedRelation(rel, keep, out._ndata[st], out._ndata[dt], keep_idx=keep_idx)
     if pending:
+        dev0 = pending[0][1].device
+        seeds = (_draw_seeds_on_device(len(pending), dev0, generator) if pending[0][3] is None
+                 else [s for _, _, _, s in pending])
         descs = ops.random_subset_select_batch([r.number_of_edges() for _, r, _, _ in pending], [k for _, _, k, _ in pending],
-                                               [s for _, _, _, s in pending], pending[0][1].device)
+                                               seeds, dev0)
         for i, (can, rel, keep, _) in enumerate(pending):
             out._rels[can] = DroppedRelation(rel, keep, out._ndata[can[0]], out._ndata[can[2]], desc=descs[i])
     if not nested:
@@ -704,7 +721,8 @@ def random_edge_dropout_sparse(adj, dropout_rate: float = 0.1, generator: Option
     return out
 
 
-def random_edge_dropout_sparse_views(adjs, dropout_rate: float = 0.1, generator: Optional[torch.Generator] = None):
+def random_edge_dropout_sparse_views(adjs, dropout_rate: float = 0.1, generator: Optional[torch.Generator] = None,
+                                     selection: Optional[str] = None):
     """``random_edge_dropout_sparse(..., as_view=True)`` for several adjacencies at once (the four
     similarity / feature graphs of a training step, augmentation.py:448-458): one seed draw per graph,
     in the given order, then ONE batched subset selection.  Returns masked ``CSRGraph`` views."""
@@ -713,12 +731,13 @@ def random_edge_dropout_sparse_views(adjs, dropout_rate: float = 0.1, generator:
     bases = [adjacency_csr(a) for a in adjs]
     if not bases:
         return []
-    if bases[0].device.type != "cuda" or (generator is not None and generator.device.type != "cpu"):
+    on_device = selection == "select_device" and bases[0].device.type == "cuda"
+    if not on_device and (bases[0].device.type != "cuda" or (generator is not None and generator.device.type != "cpu")):
         return [random_edge_dropout_sparse(a, dropout_rate, generator, as_view=True) for a in adjs]
     if any(b.survivors() is not None for b in bases):  # a dropout of dropped views: exact counts of the survivors
         return [random_edge_dropout_sparse(b, dropout_rate, generator, as_view=True) for b in bases]
     keeps = [max(1, int(b.nnz * (1 - dropout_rate))) for b in bases]
-    seeds = [_draw_seed(generator) for _ in bases]
+    seeds = _draw_seeds_on_device(len(bases), bases[0].device, generator) if on_device else [_draw_seed(generator) for _ in bases]
     descs = ops.random_subset_select_batch([b.nnz for b in bases], keeps, seeds, bases[0].device)
     return [b.dropped(descs[i]) for i, b in enumerate(bases)]
 

@@ -24,16 +24,20 @@ from .model import common_loss
 
 
 def augment(batch: Dict, edge_dropout_rate: float = 0.1, feature_noise_scale: float = 0.05,
-            sim_noise_scale: float = 0.05, generator: Optional[torch.Generator] = None) -> Dict:
+            sim_noise_scale: float = 0.05, generator: Optional[torch.Generator] = None,
+            selection: Optional[str] = None) -> Dict:
     """``augment_graph_data(..., ['edge_dropout', 'feature_noise'])`` — augmentation.py:402-489.
-    The decoder graph is not augmented (train.py:270)."""
+    The decoder graph is not augmented (train.py:270).  ``selection``: how the edge subsets are drawn
+    (``graph.random_edge_dropout``); ``"select_device"`` draws their seeds on the device — no host value, no
+    synchronisation: the form :class:`CapturedTrainStep` records."""
     out = dict(batch)
-    out["enc_graph"] = G.random_edge_dropout(batch["enc_graph"], edge_dropout_rate, generator)
+    out["enc_graph"] = G.random_edge_dropout(batch["enc_graph"], edge_dropout_rate, generator, selection=selection)
     # masked views of the cached CSRs (GraphConvolution accepts them; the reference's sparse tensors are
     # available from G.random_edge_dropout_sparse), all four subsets selected by one series of launches
     keys = [k for k in ("drug_graph", "disease_graph", "drug_feature_graph", "disease_feature_graph")
             if batch.get(k) is not None]
-    for k, view in zip(keys, G.random_edge_dropout_sparse_views([batch[k] for k in keys], edge_dropout_rate, generator)):
+    for k, view in zip(keys, G.random_edge_dropout_sparse_views([batch[k] for k in keys], edge_dropout_rate, generator,
+                                                                selection=selection)):
         out[k] = view
     for k, scale in (("drug_feat", feature_noise_scale), ("disease_feat", feature_noise_scale),
                      ("drug_sim_feat", sim_noise_scale), ("disease_sim_feat", sim_noise_scale)):
@@ -67,6 +71,55 @@ def train_step(net, optimizer, batch: Dict, labels: torch.Tensor, beta: float = 
     nn.utils.clip_grad_norm_(net.parameters(), grad_clip)
     optimizer.step()
     return loss.detach()
+
+
+class CapturedTrainStep:
+    """One training iteration (train.py:249-300: per-step augmentation, forward, loss, backward, clip, Adam) recorded
+    once as a HIP graph and replayed.  The real datasets are launch-bound on an MI355X (an lrssl-shaped step is ~600
+    small kernels: 7-9 ms eager, host-bound; ~6.5 ms of device time): a replay issues them with one call.
+
+    What makes the step recordable is that nothing in it needs the host: the edge dropout is an 8-word description
+    selected on the device (``selection="select_device"``: the subsets' seeds come from the device RNG, so every replay
+    drops different edges, exactly ``max(1, int(E (1 - p)))`` kept each time), no graph is rebuilt, the layouts are
+    cached on the un-dropped parents, dropout masks and feature noise use torch's graph-aware device generator, and the
+    optimizer must be ``capturable`` (``torch.optim.Adam(..., capturable=True)``).
+
+    ``step = CapturedTrainStep(net, opt, batch, labels); loss = step()`` — ``loss`` is a device tensor that the next
+    replay overwrites.  The model's parameters, the optimizer state and ``batch`` / ``labels`` are captured by
+    address: update them in place (``labels.copy_(...)``), never rebind them."""
+
+    def __init__(self, net, optimizer, batch: Dict, labels: torch.Tensor, beta: float = 0.1, grad_clip: float = 1.0,
+                 do_augment: bool = True, warmup: int = 3):
+        if not labels.is_cuda:
+            raise RuntimeError("CapturedTrainStep records a HIP graph: the model and its inputs must be on the GPU")
+        if not all(g.get("capturable", False) for g in optimizer.param_groups):
+            raise RuntimeError("the optimizer must be constructed with capturable=True to be recorded in a HIP graph")
+        self.net, self.optimizer = net, optimizer
+
+        def step():
+            net.train()
+            step_batch = augment(batch, selection="select_device") if do_augment else batch
+            loss, _ = forward_loss(net, step_batch, labels, beta)
+            optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            nn.utils.clip_grad_norm_(net.parameters(), grad_clip)
+            optimizer.step()
+            return loss.detach()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # lazily built layouts, plans and autotuned library kernels exist before the recording
+            for _ in range(max(1, warmup)):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = step()
+
+    def __call__(self) -> torch.Tensor:
+        self.graph.replay()
+        return self.loss
 
 
 def _binary_clf_curve(y_true: np.ndarray, y_score: np.ndarray):

@@ -826,6 +826,15 @@ def random_subset_select_batch(Es, keeps, seeds, device, e_offsets=None) -> torc
         raise RuntimeError("dream_gnn_amd ops run on the MI355X only: got device %s" % device)
     n = len(Es)
     offs = [0] * n if e_offsets is None else list(e_offsets)
+    if isinstance(seeds, torch.Tensor):
+        # seeds in device memory (int64, one per list), read by the kernels (``dgmi_random_subset_select_batch_dseed``):
+        # no host value goes into the launches, so the call can sit inside a captured HIP graph and still select new
+        # subsets on every replay
+        _require_device(seeds)
+        seeds = seeds.reshape(-1).to(torch.int64).contiguous()
+        parts = [_T.random_subset_select_batch_dseed(seeds[i:i + 8], list(Es[i:i + 8]), list(keeps[i:i + 8]), offs[i:i + 8])
+                 for i in range(0, n, 8)]
+        return parts[0] if len(parts) == 1 else torch.cat(parts)
     like = torch.empty(0, device=device)
     parts = [_T.random_subset_select_batch(like, list(Es[i:i + 8]), list(keeps[i:i + 8]),
                                            [_signed64(s) for s in seeds[i:i + 8]], offs[i:i + 8])

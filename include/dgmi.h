@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 16
+#define DGMI_ABI_VERSION 17
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -305,6 +305,10 @@ DGMI_API int dgmi_rank_add_f32(float* G, int64_t ldg, const float* coef, int64_t
  *                               E / keep / seed / e_offset arrays are HOST arrays of length n, e_offset
  *                               may be NULL; descs: n x 8 words on the device): a training step selects
  *                               8 subsets at once (train.py:267) and at dataset scale launches dominate.
+ *   dgmi_random_subset_select_batch_dseed  the same with the n seeds read from DEVICE memory (8-byte aligned) by
+ *                               the kernels: no host value is baked into the launches, so a training step captured
+ *                               as a HIP graph draws new subsets on every replay (the seeds are refreshed by a
+ *                               device-side RNG inside the same graph).
  *   dgmi_keep_mask_f32          mask[e] = 1.0f / 0.0f for e in [0, E) under n_keep descriptions.
  *   dgmi_random_subset_mask_f32 both in one call (e_offset = 0).
  */
@@ -316,6 +320,10 @@ DGMI_API int dgmi_random_subset_select_batch(int32_t n, const int64_t* E /* host
                                              const uint64_t* seed /* host */, const uint32_t* e_offset /* host */,
                                              uint32_t* descs, void* workspace, size_t workspace_bytes,
                                              dgmi_stream_t stream);
+DGMI_API int dgmi_random_subset_select_batch_dseed(int32_t n, const int64_t* E /* host */, const int64_t* keep /* host */,
+                                                   const uint64_t* seed_dev /* device */, const uint32_t* e_offset /* host */,
+                                                   uint32_t* descs, void* workspace, size_t workspace_bytes,
+                                                   dgmi_stream_t stream);
 DGMI_API int dgmi_keep_mask_f32(const uint32_t* keep, int32_t n_keep, int64_t E, float* mask,
                                 dgmi_stream_t stream);
 DGMI_API int dgmi_random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask,

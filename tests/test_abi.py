@@ -22,6 +22,7 @@ def test_header_declares_the_expected_entry_points():
                            "dgmi_knn_cosine_workspace_bytes",
                            "dgmi_probe_row_gather_f32",
                            "dgmi_random_subset_mask_f32", "dgmi_random_subset_select", "dgmi_random_subset_select_batch",
+                           "dgmi_random_subset_select_batch_dseed",
                            "dgmi_random_subset_workspace_bytes", "dgmi_rank_add_f32", "dgmi_scale_rows_f32",
                            "dgmi_spmm_csr_f32", "dgmi_spmm_csr_planned_f32", "dgmi_spmm_default_chunk",
                            "dgmi_spmm_partials_bytes", "dgmi_spmm_plan_build", "dgmi_spmm_plan_bytes",

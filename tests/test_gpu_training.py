@@ -81,3 +81,71 @@ def test_training_step_with_augmentation_runs_on_device(dev):
     assert all(np.isfinite(losses))
     auroc, aupr = H.evaluate(net, batch, labels)
     assert 0 <= auroc <= 1 and 0 <= aupr <= 1
+
+
+def test_subsets_from_device_seeds_are_exact_and_follow_the_seed(oracle, dev):
+    """``selection="select_device"`` (dgmi_random_subset_select_batch_dseed): the kernels read the seeds from device
+    memory.  Each description carries the seed it was made with; the oracle's mask for (seed, E, keep) is the
+    kernel's mask, bit for bit — for a short list (one-workgroup select) and a long one (window passes)."""
+    from dream_gnn_amd import ops
+
+    Es, keeps = [5000, 300_000, 1, 70_000], [4500, 123_457, 1, 0]
+    seeds = torch.tensor([11, 2 ** 61 + 12345, 7, 99], dtype=torch.int64, device=dev)
+    descs = ops.random_subset_select_batch(Es, keeps, seeds, dev)
+    host = ops.random_subset_select_batch(Es, keeps, [int(s) for s in seeds.tolist()], dev)
+    assert torch.equal(descs, host)  # the same selection, wherever the seed comes from
+    for i, (E, keep) in enumerate(zip(Es, keeps)):
+        m = ops.keep_mask(descs[i:i + 1], E).cpu().numpy()
+        assert int(m.sum()) == keep
+        want = oracle.random_subset_mask(E, keep, int(seeds[i]))
+        assert np.array_equal(m, want)
+    # fresh device draws give fresh subsets, each of the exact size
+    from dream_gnn_amd import graph as G
+    a = G._draw_seeds_on_device(2, dev, None)
+    d2 = ops.random_subset_select_batch([70_000, 70_000], [63_000, 63_000], a, dev)
+    m0, m1 = ops.keep_mask(d2[0:1], 70_000), ops.keep_mask(d2[1:2], 70_000)
+    assert int(m0.sum()) == 63_000 and int(m1.sum()) == 63_000 and not torch.equal(m0, m1)
+
+
+def test_captured_training_step_equals_the_eager_one_without_randomness(dev):
+    """harness.CapturedTrainStep with every stochastic piece off (no augmentation, dropout 0): K replays of the
+    recorded HIP graph move the parameters exactly where K eager steps move them (same kernels, same order)."""
+    from dream_gnn_amd import harness as H, model as M
+
+    batch, labels, args = _problem(dev)
+    warm, K = 2, 4
+
+    def fresh():
+        torch.manual_seed(123)
+        net = M.Net(args).to(dev)
+        return net, torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-5, capturable=True)
+
+    net_e, opt_e = fresh()
+    eager = [float(H.train_step(net_e, opt_e, batch, labels, beta=0.1, do_augment=False)) for _ in range(warm + K)]
+    net_c, opt_c = fresh()
+    step = H.CapturedTrainStep(net_c, opt_c, batch, labels, beta=0.1, do_augment=False, warmup=warm)
+    captured = [float(step()) for _ in range(K)]
+    assert max(abs(a - b) for a, b in zip(eager[warm:], captured)) <= 1e-5, (eager, captured)
+    for (k, pe), pc in zip(net_e.state_dict().items(), net_c.state_dict().values()):
+        assert float((pe - pc).abs().max()) <= 1e-5 * max(1.0, float(pe.abs().max())), k
+    with pytest.raises(RuntimeError):  # an optimizer that would synchronise cannot be recorded
+        H.CapturedTrainStep(net_c, torch.optim.Adam(net_c.parameters()), batch, labels)
+
+
+def test_captured_training_step_with_the_reference_augmentation(dev):
+    """The whole iteration of train.py:249-300 as one HIP graph, per-step edge dropout and feature noise included:
+    every replay draws new subsets on the device (the losses differ from replay to replay) and the model trains."""
+    from dream_gnn_amd import harness as H, model as M
+
+    batch, labels, args = _problem(dev)
+    args.dropout, args.attention_dropout = 0.1, 0.1
+    torch.manual_seed(1)
+    net = M.Net(args).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-5, capturable=True)
+    step = H.CapturedTrainStep(net, opt, batch, labels, beta=0.1)
+    losses = [float(step()) for _ in range(40)]
+    assert all(np.isfinite(losses)) and len(set(round(x, 7) for x in losses)) > 30
+    assert np.mean(losses[-10:]) < np.mean(losses[:10])
+    # the un-augmented inputs were not touched by the recorded augmentation
+    auroc, aupr = H.evaluate(net, batch, labels)
+    assert 0.0 <= auroc <= 1.0 and 0.0 <= aupr <= 1.0
