@@ -107,16 +107,39 @@ __device__ void block_select(int64_t E, int64_t keep, uint64_t seed, uint32_t e_
       if ((h & pmask) == prefix) atomicAdd(&hist[(h >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (t == 0) {  // the bin holding the `rem`-th smallest candidate becomes the next prefix byte
-      int64_t rem = sh_rem, before = 0;
-      uint32_t b = 0;
-      for (; b < 255u; ++b) {
-        if (before + hist[b] >= rem) break;
-        before += hist[b];
+    if (t < 64) {
+      // The bin holding the `rem`-th smallest candidate becomes the next prefix byte: the first bin whose running count
+      // reaches rem (bin 255 if none does).  Wave 0 finds it with a scan over 64 groups of 4 bins — one thread walking
+      // 256 dependent LDS reads took ~10 us per pass, 43 us per selection of a 3 k-edge list (rocprofv3 of a training step).
+      const int64_t rem = sh_rem;
+      const uint32_t c0 = hist[4 * t], c1 = hist[4 * t + 1], c2 = hist[4 * t + 2], c3 = hist[4 * t + 3];
+      const int64_t own = (int64_t)c0 + c1 + c2 + c3;
+      int64_t inc = own;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int64_t y = __shfl_up(inc, off, 64);
+        if (t >= off) inc += y;
       }
-      sh_rem = rem - before;
-      sh_prefix = prefix | (b << shift);
-      sh_mask = pmask | (255u << shift);
+      const unsigned long long reached = __ballot(inc >= rem);
+      const int owner = reached ? __ffsll((long long)reached) - 1 : 63;
+      if (t == owner) {
+        int64_t before = inc - own;
+        uint32_t b = 4u * (uint32_t)t;
+        if (before + c0 < rem) {
+          before += c0;
+          ++b;
+          if (before + c1 < rem) {
+            before += c1;
+            ++b;
+            if (before + c2 < rem) {
+              before += c2;
+              ++b;
+            }
+          }
+        }
+        sh_rem = rem - before;
+        sh_prefix = prefix | (b << shift);
+        sh_mask = pmask | (255u << shift);
+      }
     }
     __syncthreads();
   }
@@ -222,17 +245,32 @@ __global__ __launch_bounds__(kBlock) void window_pick_kernel(BatchParams p, Sele
   for (int j = 0; j < kPer; ++j) s += st->hist[threadIdx.x * kPer + j];
   part[threadIdx.x] = s;
   __syncthreads();
-  if (threadIdx.x != 0) return;
+  if (threadIdx.x >= 64) return;
+  // wave 0: the first thread-group (of kPer bins) whose running count reaches rem — a scan over 64 lanes x 4 groups
+  // instead of one thread walking 2 x 256 dependent LDS reads (12 us)
+  const int lane = threadIdx.x;
   const int64_t rem = p.keep[blockIdx.y] - (int64_t)st->below;  // rank of the key among hashes >= lo
-  unsigned long long total = 0;
-  for (int t = 0; t < kBlock; ++t) total += part[t];
+  unsigned long long g[kBlock / 64];
+  unsigned long long own = 0;
+  for (int j = 0; j < kBlock / 64; ++j) {
+    g[j] = part[lane * (kBlock / 64) + j];
+    own += g[j];
+  }
+  unsigned long long inc = own;
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long y = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += y;
+  }
+  const unsigned long long total = __shfl(inc, 63, 64);
   if (rem <= 0 || (unsigned long long)rem > total) {  // the window missed the threshold
-    st->mode = kFallback;
+    if (lane == 0) st->mode = kFallback;
     return;
   }
-  unsigned long long before = 0;
-  int t = 0;
-  for (; t < kBlock - 1 && before + part[t] < (unsigned long long)rem; ++t) before += part[t];
+  const unsigned long long reached = __ballot(inc >= (unsigned long long)rem);
+  if (lane != __ffsll((long long)reached) - 1) return;  // rem <= total: some lane reaches it
+  unsigned long long before = inc - own;
+  int t = lane * (kBlock / 64);
+  for (int j = 0; j < kBlock / 64 - 1 && before + g[j] < (unsigned long long)rem; ++j, ++t) before += g[j];
   int b = t * kPer;
   for (; b < t * kPer + kPer - 1 && before + st->hist[b] < (unsigned long long)rem; ++b) before += st->hist[b];
   st->remaining = rem - (int64_t)before;
@@ -324,7 +362,12 @@ hipError_t random_subset_select_batch(int n, const int64_t* E, const int64_t* ke
   const dim3 one(1, (unsigned)n);
   hipLaunchKernelGGL(select_or_init_kernel, one, dim3(kSelectThreads), 0, s, p, st, out);
   if (e_max > 0) {
-    const dim3 wide(grid_for(e_max), (unsigned)n);
+    // >= 16 edges per thread: every block ends in ONE atomic on its list's `below` counter, and 1816 blocks of a
+    // 465 k-edge list queued 30 us of them on that one address (rocprofv3 of a training step)
+    int64_t wb = (e_max + (int64_t)kBlock * 16 - 1) / ((int64_t)kBlock * 16);
+    if (wb < 1) wb = 1;
+    if (wb > 2048) wb = 2048;
+    const dim3 wide((unsigned)wb, (unsigned)n);
     hipLaunchKernelGGL(window_hist_kernel, wide, dim3(kBlock), 0, s, p, st);
     hipLaunchKernelGGL(window_pick_kernel, one, dim3(kBlock), 0, s, p, st);
     hipLaunchKernelGGL(window_collect_kernel, wide, dim3(kBlock), 0, s, p, st);
