@@ -287,7 +287,7 @@ class _Structure:
     """Everything about a CSRGraph that depends on the edge list only (shared by value views)."""
 
     __slots__ = ("n_dst", "n_src", "dst", "src", "indptr", "indices", "eid", "plan", "planned", "t",
-                 "sliced", "sliced_t", "regular", "regular_t", "validated", "split", "split_t")
+                 "sliced", "sliced_t", "regular", "regular_t", "validated", "split", "split_t", "max_deg", "max_deg_t")
 
 
 # Rows longer than this are cut into virtual rows before the XCD-local kernel sees them (power-law
@@ -360,6 +360,7 @@ class CSRGraph:
         S.indptr, S.indices, S.eid, flag = csr_from_coo(S.dst, S.src, S.n_dst, S.n_src, return_flag=True)
         S.planned = planned
         S.t = S.sliced = S.sliced_t = S.split = S.split_t = None
+        S.max_deg = S.max_deg_t = None  # longest row of the CSR / of the transposed CSR, once a readback has told
         S.validated = bool(check_range)
         # `regular`: no destination row is extremely long, so the XCD-local kernel (which walks a
         # (row, slice) segment sequentially) is safe to use.  Known after the one readback below;
@@ -496,6 +497,7 @@ class CSRGraph:
             if dlo < 0 or dhi >= S.n_dst:
                 raise RuntimeError("destination id out of range [0, %d): min %d max %d" % (S.n_dst, dlo, dhi))
             raise RuntimeError("source id out of range [0, %d): min %d max %d" % (S.n_src, slo, shi))
+        S.max_deg = int(max_deg)
         S.regular = self._is_regular(int(max_deg), self.nnz, S.n_dst)
 
     def _use_sliced(self, F: int, n_rows: int, n_cols: int, regular: bool) -> bool:
@@ -520,6 +522,16 @@ class CSRGraph:
         if F % 4 != 0 or n_virtual_bound * SlicedCSR.N_SLICES >= 2 ** 31 - 1 or table < SPLIT_MIN_TABLE_BYTES:
             return False
         return table <= _table_cap(SPLIT_TIERS, self.nnz / max(n_virtual_bound, 1))
+
+    @staticmethod
+    def _plan_if_needed(plan, max_deg):
+        """A plan only cuts rows longer than its chunk; when a readback has told that none is (every kNN-4 graph, every
+        small slice), the wave-per-row launch does the same work in ONE launch — the planned form's second kernel,
+        which adds the chunks of long rows, would start, find none and leave: 4-5 us each, 16 of them per training step
+        at the reference's dataset sizes."""
+        if plan is not None and max_deg is not None and max_deg <= plan.chunk:
+            return None
+        return plan
 
     def _t_struct(self):
         S = self._S
@@ -558,7 +570,8 @@ class CSRGraph:
                 S.split = _SplitSliced(S.indptr, S.eid, S.src, S.n_dst, S.n_src)
             return S.split.spmm(X, _prep_scale(src_scale, S.n_src, "src_scale"), _prep_scale(dst_scale, S.n_dst, "dst_scale"),
                                 out, self._vals_for("split", S.split.sliced.eid), keep=self._keep, epi=epi)
-        return self._run(S.indptr, S.indices, self.vals, S.plan, S.n_dst, S.n_src, X, src_scale, dst_scale, out, S.eid, epi)
+        return self._run(S.indptr, S.indices, self.vals, self._plan_if_needed(S.plan, S.max_deg), S.n_dst, S.n_src, X,
+                         src_scale, dst_scale, out, S.eid, epi)
 
     def spmm_t(self, dY, src_scale=None, dst_scale=None, out=None):
         """``diag(src_scale) A^T diag(dst_scale) dY`` — the backward of :meth:`spmm`."""
@@ -566,6 +579,7 @@ class CSRGraph:
         indptr_t, indices_t, eid_t, plan_t = self._t_struct()
         if S.regular_t is None:  # one-time readback of the reversed graph's maximum degree
             max_deg = int((indptr_t[1:] - indptr_t[:-1]).max()) if self.nnz else 0
+            S.max_deg_t = max_deg
             S.regular_t = self._is_regular(max_deg, self.nnz, S.n_src)
         if dY.dim() == 2 and self._use_sliced(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):
             if S.sliced_t is None:
@@ -577,7 +591,7 @@ class CSRGraph:
                 S.split_t = _SplitSliced(indptr_t, eid_t, S.dst, S.n_src, S.n_dst)
             return S.split_t.spmm(dY, _prep_scale(dst_scale, S.n_dst, "dst_scale"), _prep_scale(src_scale, S.n_src, "src_scale"),
                                   out, self._vals_for("split_t", S.split_t.sliced.eid), keep=self._keep)
-        return self._run(indptr_t, indices_t, self._vals_for("csr_t", eid_t), plan_t, S.n_src, S.n_dst, dY,
+        return self._run(indptr_t, indices_t, self._vals_for("csr_t", eid_t), self._plan_if_needed(plan_t, S.max_deg_t), S.n_src, S.n_dst, dY,
                          dst_scale, src_scale, out, eid_t)
 
 
