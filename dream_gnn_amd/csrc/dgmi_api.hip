@@ -297,9 +297,9 @@ DGMI_API int dgmi_gather_add_f32(const int32_t* src, const int32_t* dst, int64_t
 
 DGMI_API int dgmi_epilogue_backward_f32(const float* dY, const float* Y, const float* mask, int64_t n, int32_t act,
                                         float act_slope, float mask_scale, float* out, dgmi_stream_t stream) {
-  if (n < 0 || (act != 0 && act != 1)) return DGMI_ERR_INVALID_ARG;
+  if (n < 0 || act < 0 || act > 2 || (act == 2 && mask != nullptr)) return DGMI_ERR_INVALID_ARG;
   if (n == 0) return DGMI_OK;
-  if (dY == nullptr || out == nullptr || (act == 1 && Y == nullptr)) return DGMI_ERR_INVALID_ARG;
+  if (dY == nullptr || out == nullptr || (act != 0 && Y == nullptr)) return DGMI_ERR_INVALID_ARG;
   return from_hip(dgmi::epilogue_backward_f32(dY, Y, mask, n, act, act_slope, mask_scale, out, as_stream(stream)));
 }
 

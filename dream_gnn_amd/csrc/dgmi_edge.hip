@@ -184,6 +184,10 @@ __global__ __launch_bounds__(256) void epilogue_backward_kernel(const float* __r
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     float g = dY[i];
+    if (act == 2) {  // Y = dropout(relu(z)): Y > 0 exactly where z > 0 and the element was kept; no mask tensor needed
+      out[i] = Y[i] > 0.f ? g * mask_scale : 0.f;
+      continue;
+    }
     if (act == 1) g = Y[i] > 0.f ? g : g * slope;
     if (mask != nullptr) g *= mask[i] * mask_scale;
     out[i] = g;

@@ -253,6 +253,10 @@ DGMI_API int dgmi_gather_add_f32(const int32_t* src, const int32_t* dst, int64_t
  * Backward of the fused output epilogue over n contiguous elements:
  *   out[i] = dY[i] * (act == 1 ? (Y[i] > 0 ? 1 : act_slope) : 1) * (mask ? mask[i] * mask_scale : 1)
  * where Y is the epilogue's output (layers.py:134-138 backward: dropout then activation).
+ *   act == 2 (mask must be NULL): Y = dropout(relu(z)) as the decoder applies it after each Linear
+ *   (layers.py:366-369): out[i] = Y[i] > 0 ? dY[i] * mask_scale : 0 — Y is positive exactly where z was positive
+ *   AND the element was kept, so the backward of both needs neither z nor the dropout mask, and is one pass
+ *   instead of two.
  */
 DGMI_API int dgmi_epilogue_backward_f32(const float* dY, const float* Y, const float* mask, int64_t n,
                                         int32_t act, float act_slope, float mask_scale, float* out,

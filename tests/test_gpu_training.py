@@ -149,3 +149,28 @@ def test_captured_training_step_with_the_reference_augmentation(dev):
     # the un-augmented inputs were not touched by the recorded augmentation
     auroc, aupr = H.evaluate(net, batch, labels)
     assert 0.0 <= auroc <= 1.0 and 0.0 <= aupr <= 1.0
+
+
+def test_decoder_relu_dropout_backward_in_one_pass(dev):
+    """model._ReluDropout: dropout(relu(x)) forward exactly as torch (same values, same RNG consumption), backward from
+    the output alone (dgmi_epilogue_backward_f32 act 2) — bit-equal to torch's two-pass backward."""
+    from dream_gnn_amd import model as M
+
+    E, W, p = M._EdgeLinear.MIN_ROWS + 77, 64, 0.3
+    x = torch.randn(E, W, device=dev)
+    x[5, :8] = 0.0  # exact zeros: relu'(0) = 0 either way
+    w = torch.randn(E, W, device=dev)
+    drop = torch.nn.Dropout(p).train()
+    xa = x.clone().requires_grad_(True)
+    torch.manual_seed(77)
+    ya = drop(torch.relu(xa))
+    (ya * w).sum().backward()
+    xb = x.clone().requires_grad_(True)
+    torch.manual_seed(77)
+    yb = M._relu_dropout(drop, xb)
+    assert yb.grad_fn is not None and "ReluDropout" in type(yb.grad_fn).__name__
+    (yb * w).sum().backward()
+    assert torch.equal(ya, yb) and torch.equal(xa.grad, xb.grad)
+    # eval mode, short inputs and p = 0 take torch's own path
+    assert "ReluDropout" not in type(M._relu_dropout(torch.nn.Dropout(p).eval(), xb).grad_fn).__name__
+    assert "ReluDropout" not in type(M._relu_dropout(drop, xb[:100]).grad_fn).__name__
