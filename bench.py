@@ -719,10 +719,16 @@ def main():
         if other is not None:
             out["edge_scaled" if args.scale == "nodes" else "node_scaled"] = other
         if world == 1 and not args.no_variants:
-            out["variants"] = variants(torch, dev, ops)
+            try:  # extra products beside the judged step: a failure here must not cost the line
+                out["variants"] = variants(torch, dev, ops)
+            except Exception as exc:  # noqa: BLE001
+                out["variants"] = {"error": repr(exc)}
             out["model_steps"] = model_steps_in_child()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(torch, ops)
+            try:
+                out["cpu_baseline"] = cpu_baseline(torch, ops)
+            except Exception as exc:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
