@@ -142,10 +142,13 @@ def test_captured_training_step_with_the_reference_augmentation(dev):
     torch.manual_seed(1)
     net = M.Net(args).to(dev)
     opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-5, capturable=True)
+    net.eval()
+    with torch.no_grad():
+        untrained = float(H.forward_loss(net, batch, labels, 0.1)[0])
     step = H.CapturedTrainStep(net, opt, batch, labels, beta=0.1)
     losses = [float(step()) for _ in range(40)]
     assert all(np.isfinite(losses)) and len(set(round(x, 7) for x in losses)) > 30
-    assert np.mean(losses[-10:]) < np.mean(losses[:10])
+    assert np.mean(losses[-10:]) < 0.8 * untrained, (untrained, losses[-10:])
     # the un-augmented inputs were not touched by the recorded augmentation
     auroc, aupr = H.evaluate(net, batch, labels)
     assert 0.0 <= auroc <= 1.0 and 0.0 <= aupr <= 1.0
