@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgmi.so")
 TORCH_LIB_PATH = os.path.join(_HERE, "libdgmi_torch.so")  # the dreamgnn_mi::* dispatcher ops over the C ABI
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # name -> (restype, argtypes); mirrors include/dgmi.h one to one.
 _vp = ctypes.c_void_p
@@ -44,7 +44,7 @@ SIGNATURES = {
     "dgmi_knn_cosine_topk_f32": (ctypes.c_int, [_vp, _i64, _i64, _i64, ctypes.c_int32, _vp, _vp, ctypes.c_size_t, _vp]),
     "dgmi_probe_row_gather_f32": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int32, _vp, _vp]),
     "dgmi_epilogue_backward_f32": (ctypes.c_int, [_vp, _vp, _vp, _i64, ctypes.c_int32, ctypes.c_float, ctypes.c_float, _vp, _vp]),
-    "dgmi_gather_add_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "dgmi_gather_add_f32": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, ctypes.c_int32, _vp]),
     "dgmi_random_subset_workspace_bytes": (ctypes.c_size_t, []),
     "dgmi_random_subset_mask_f32": (ctypes.c_int, [_i64, _i64, ctypes.c_uint64, _vp, _vp, ctypes.c_size_t, _vp]),
     "dgmi_spmm_default_chunk": (ctypes.c_int32, [_i64, _i64]),

@@ -285,14 +285,14 @@ DGMI_API int dgmi_gather_concat_f32(const int32_t* src, const int32_t* dst, int6
 
 DGMI_API int dgmi_gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
                                  int64_t lda, const float* B, int64_t ldb, const float* bias, int64_t F,
-                                 float* out, int64_t ldo, dgmi_stream_t stream) {
-  if (E < 0 || F < 0) return DGMI_ERR_INVALID_ARG;
+                                 float* out, int64_t ldo, int32_t act, dgmi_stream_t stream) {
+  if (E < 0 || F < 0 || (act != 0 && act != 1)) return DGMI_ERR_INVALID_ARG;
   if (E > INT32_MAX || F > INT32_MAX) return DGMI_ERR_TOO_LARGE;
   if (E == 0 || F == 0) return DGMI_OK;
   if (src == nullptr || dst == nullptr || A == nullptr || B == nullptr || out == nullptr)
     return DGMI_ERR_INVALID_ARG;
   if (lda < F || ldb < F || ldo < F) return DGMI_ERR_INVALID_ARG;
-  return from_hip(dgmi::gather_add_f32(src, dst, E, A, lda, B, ldb, bias, F, out, ldo, as_stream(stream)));
+  return from_hip(dgmi::gather_add_f32(src, dst, E, A, lda, B, ldb, bias, F, out, ldo, act, as_stream(stream)));
 }
 
 DGMI_API int dgmi_epilogue_backward_f32(const float* dY, const float* Y, const float* mask, int64_t n, int32_t act,

@@ -81,7 +81,7 @@ template <int VEC, bool HAS_BIAS>
 __global__ __launch_bounds__(kBlock) void gather_add_kernel(
     const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t E,
     const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
-    const float* __restrict__ bias, int W, float* __restrict__ out, int64_t ldo) {
+    const float* __restrict__ bias, int W, float* __restrict__ out, int64_t ldo, int act) {
   const int64_t total = E * W;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
@@ -104,10 +104,17 @@ __global__ __launch_bounds__(kBlock) void gather_add_kernel(
         x.z += z.z;
         x.w += z.w;
       }
+      if (act == 1) {  // relu in the pass that writes the E x F result (the decoder's next op, layers.py:366)
+        x.x = fmaxf(x.x, 0.f);
+        x.y = fmaxf(x.y, 0.f);
+        x.z = fmaxf(x.z, 0.f);
+        x.w = fmaxf(x.w, 0.f);
+      }
       *reinterpret_cast<float4*>(o) = x;
     } else {
       float x = a[0] + b[0];
       if (HAS_BIAS) x += bias[c];
+      if (act == 1) x = fmaxf(x, 0.f);
       o[0] = x;
     }
   }
@@ -150,7 +157,7 @@ hipError_t gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, 
 
 hipError_t gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A, int64_t lda,
                           const float* B, int64_t ldb, const float* bias, int64_t F, float* out,
-                          int64_t ldo, hipStream_t s) {
+                          int64_t ldo, int act, hipStream_t s) {
   if (E == 0 || F == 0) return hipSuccess;
   const bool vec = (F % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (ldo % 4 == 0) && al16(A) &&
                    al16(B) && al16(out) && (bias == nullptr || al16(bias));
@@ -158,18 +165,18 @@ hipError_t gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, con
     const int W = (int)(F / 4);
     if (bias)
       hipLaunchKernelGGL((gather_add_kernel<4, true>), dim3(grid_for(E * W)), dim3(kBlock), 0, s, src, dst, E,
-                         A, lda, B, ldb, bias, W, out, ldo);
+                         A, lda, B, ldb, bias, W, out, ldo, act);
     else
       hipLaunchKernelGGL((gather_add_kernel<4, false>), dim3(grid_for(E * W)), dim3(kBlock), 0, s, src, dst, E,
-                         A, lda, B, ldb, bias, W, out, ldo);
+                         A, lda, B, ldb, bias, W, out, ldo, act);
   } else {
     const int W = (int)F;
     if (bias)
       hipLaunchKernelGGL((gather_add_kernel<1, true>), dim3(grid_for(E * W)), dim3(kBlock), 0, s, src, dst, E,
-                         A, lda, B, ldb, bias, W, out, ldo);
+                         A, lda, B, ldb, bias, W, out, ldo, act);
     else
       hipLaunchKernelGGL((gather_add_kernel<1, false>), dim3(grid_for(E * W)), dim3(kBlock), 0, s, src, dst, E,
-                         A, lda, B, ldb, bias, W, out, ldo);
+                         A, lda, B, ldb, bias, W, out, ldo, act);
   }
   return hipGetLastError();
 }

@@ -157,7 +157,7 @@ hipError_t gather_concat_f32(const int32_t* src, const int32_t* dst, int64_t E, 
 // out[e] = A[src[e]] + B[dst[e]] (+ bias)   (dgmi_edge.hip)
 hipError_t gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A, int64_t lda,
                           const float* B, int64_t ldb, const float* bias, int64_t F, float* out,
-                          int64_t ldo, hipStream_t s);
+                          int64_t ldo, int act, hipStream_t s);  // act 1: relu applied to the sum
 
 // g = dY * act'(Y) * mask * mask_scale over n contiguous elements: backward of the fused epilogue (dgmi_edge.hip)
 hipError_t epilogue_backward_f32(const float* dY, const float* Y, const float* mask, int64_t n, int act, float slope,

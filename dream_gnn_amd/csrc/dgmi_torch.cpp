@@ -328,7 +328,8 @@ Tensor gather_concat_raw(const Tensor& src, const Tensor& dst, const Tensor& A, 
   return out;
 }
 
-Tensor gather_add_raw(const Tensor& src, const Tensor& dst, const Tensor& A, const Tensor& B, const OptTensor& bias) {
+Tensor gather_add_raw(const Tensor& src, const Tensor& dst, const Tensor& A, const Tensor& B, const OptTensor& bias, int64_t act) {
+  TORCH_CHECK(act == 0 || act == 1, "act must be 0 (none) or 1 (relu)");
   check(src, at::kInt, 1, "src", src);
   check(dst, at::kInt, 1, "dst", src);
   TORCH_CHECK(src.numel() == dst.numel(), "src/dst length mismatch");
@@ -341,7 +342,7 @@ Tensor gather_add_raw(const Tensor& src, const Tensor& dst, const Tensor& A, con
   Tensor out = at::empty({E, a.F}, a.t.options());
   check_status(dgmi_gather_add_f32(src.data_ptr<int32_t>(), dst.data_ptr<int32_t>(), E, a.t.data_ptr<float>(), a.ld,
                                    b.t.data_ptr<float>(), b.ld, (const float*)optptr(bias), a.F, out.data_ptr<float>(),
-                                   a.F > 0 ? a.F : 1, stream_of(src)), "dgmi_gather_add_f32");
+                                   a.F > 0 ? a.F : 1, (int32_t)act, stream_of(src)), "dgmi_gather_add_f32");
   return out;
 }
 
@@ -585,7 +586,7 @@ TORCH_LIBRARY(dreamgnn_mi, m) {
   m.def("colsum_rows_backward_(Tensor(a!) gf, Tensor coef, Tensor gs, int n, int R, int i0) -> ()");
   m.def("gather_f32(Tensor values, Tensor perm) -> Tensor");
   m.def("gather_concat_raw(Tensor src, Tensor dst, Tensor A, Tensor B) -> Tensor");
-  m.def("gather_add_raw(Tensor src, Tensor dst, Tensor A, Tensor B, Tensor? bias) -> Tensor");
+  m.def("gather_add_raw(Tensor src, Tensor dst, Tensor A, Tensor B, Tensor? bias, int act=0) -> Tensor");
   m.def("random_subset_select(Tensor like, int E, int keep, int seed, int e_offset=0) -> Tensor");
   m.def("random_subset_select_batch(Tensor like, int[] E, int[] keep, int[] seed, int[] e_offset) -> Tensor");
   m.def("random_subset_select_batch_dseed(Tensor seeds, int[] E, int[] keep, int[] e_offset) -> Tensor");

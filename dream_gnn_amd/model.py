@@ -94,6 +94,48 @@ def _relu_dropout(drop: nn.Dropout, x):
     return drop(F.relu(x))
 
 
+class _EdgeLinearReluDropout(torch.autograd.Function):
+    """``dropout(relu(x W^T + b))`` over the edge list (the decoder's ``lin2`` stage, layers.py:368): the relu is the
+    GEMM's own epilogue (``torch._addmm_activation``: 204 -> 165 us at 467 k x 128 -> 64), the dropout torch's, the backward
+    ONE gating pass from the output, then the library GEMM for the input gradient and the split-K weight gradient of
+    :class:`_EdgeLinear`."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, p: float):
+        y = torch._addmm_activation(bias, x, weight.t())  # relu(x W^T + b)
+        y = F.dropout(y, p, True)
+        ctx.scale = 1.0 / (1.0 - p)
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dz = ops.epilogue_backward(dy.contiguous(), y, None, 2, 0.0, ctx.scale)
+        dx = dz @ weight if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            c = _EdgeLinear.CHUNK
+            n = x.shape[0] // c * c
+            dw = torch.bmm(dz[:n].view(-1, c, dz.shape[1]).transpose(1, 2), x[:n].view(-1, c, x.shape[1])).sum(0)
+            if n < x.shape[0]:
+                dw = dw + dz[n:].t() @ x[n:]
+        if ctx.needs_input_grad[2]:
+            db = dz.sum(0)
+        return dx, dw, db, None
+
+
+def _fusable(drop: nn.Dropout, x) -> bool:
+    return (x.is_cuda and drop.training and 0.0 < drop.p < 1.0 and torch.is_grad_enabled() and x.dtype == torch.float32
+            and x.dim() == 2 and x.is_contiguous() and x.shape[0] >= _EdgeLinear.MIN_ROWS)
+
+
+def _edge_linear_relu_dropout(lin: nn.Linear, drop: nn.Dropout, x):
+    if _fusable(drop, x) and lin.bias is not None and lin.weight.shape[0] > 1 and hasattr(torch, "_addmm_activation"):
+        return _EdgeLinearReluDropout.apply(x, lin.weight, lin.bias, float(drop.p))
+    return _relu_dropout(drop, _edge_linear(lin, x))
+
+
 def _edge_linear(lin: nn.Linear, x):
     if x.is_cuda and x.dim() == 2 and x.shape[0] >= _EdgeLinear.MIN_ROWS and x.is_contiguous() and torch.is_grad_enabled():
         return _EdgeLinear.apply(x, lin.weight, lin.bias)
@@ -128,14 +170,17 @@ class MLPDecoder(nn.Module):
         if self.fuse_lin1:
             Fd = drug_feat.shape[1]
             w = self.lin1.weight
-            out = ops.gather_add(pairs, drug_feat @ w[:, :Fd].t(), dis_feat @ w[:, Fd:].t(), self.lin1.bias)
-            out = _relu_dropout(self.dropout, out)
+            a, b = drug_feat @ w[:, :Fd].t(), dis_feat @ w[:, Fd:].t()
+            if a.is_cuda and self.dropout.training and 0.0 < self.dropout.p < 1.0 and torch.is_grad_enabled():
+                out = ops.gather_add_relu_dropout(pairs, a, b, self.lin1.bias, self.dropout.p)
+            else:
+                out = self.dropout(F.relu(ops.gather_add(pairs, a, b, self.lin1.bias)))
         else:
             # layers.py:361-365: graph.apply_edges(udf_u_mul_e) -> edata['m'] = cat(h_src, h_dst);
             # one fused HIP gather-concat over the decoder edge list (bit-identical values).
             out = ops.gather_concat(pairs, drug_feat, dis_feat)
             out = _relu_dropout(self.dropout, _edge_linear(self.lin1, out))
-        out = _relu_dropout(self.dropout, _edge_linear(self.lin2, out))
+        out = _edge_linear_relu_dropout(self.lin2, self.dropout, out)
         return _edge_linear(self.lin3, out)
 
 

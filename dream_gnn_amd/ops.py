@@ -763,11 +763,12 @@ def gather_concat(pairs: EdgePairs, A: torch.Tensor, B: torch.Tensor) -> torch.T
     return _GatherConcat.apply(A, B, pairs)
 
 
-def gather_add_raw(src, dst, A, B, bias=None, out=None, n_src=None, n_dst=None) -> torch.Tensor:
-    """``out[e] = A[src[e]] + B[dst[e]] (+ bias)`` through ``dgmi_gather_add_f32`` (no autograd)."""
+def gather_add_raw(src, dst, A, B, bias=None, out=None, n_src=None, n_dst=None, act: int = 0) -> torch.Tensor:
+    """``out[e] = A[src[e]] + B[dst[e]] (+ bias)`` through ``dgmi_gather_add_f32`` (no autograd); ``act=1``: relu of it,
+    in the same pass."""
     _require_device(src, dst, A, B, bias, out)
     _check_tables(A, B, n_src, n_dst)
-    y = _T.gather_add_raw(src, dst, A, B, bias)
+    y = _T.gather_add_raw(src, dst, A, B, bias, int(act))
     if out is not None:
         out.copy_(y)
         return out
@@ -793,6 +794,37 @@ class _GatherAdd(torch.autograd.Function):
 def gather_add(pairs: EdgePairs, A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None):
     """Differentiable ``A[src] + B[dst] (+ bias)`` over the decoder edges."""
     return _GatherAdd.apply(A, B, bias, pairs)
+
+
+class _GatherAddReluDropout(torch.autograd.Function):
+    """``dropout(relu(A[src] + B[dst] + bias))`` — the decoder's first stage (layers.py:364-367 with ``lin1`` folded
+    into the node tables).  Forward: the relu rides in the gather-add kernel's store (one E x F pass less), the dropout
+    is torch's own (same RNG consumption as ``nn.Dropout`` on that shape).  Backward: ONE gating pass from the output
+    (``y > 0`` exactly where the sum was positive and the element was kept: ``dgmi_epilogue_backward_f32`` act 2), then
+    the two segment sums of :class:`_GatherAdd`."""
+
+    @staticmethod
+    def forward(ctx, A, B, bias, pairs: EdgePairs, p: float):
+        y = gather_add_raw(pairs.src, pairs.dst, A, B, bias, n_src=pairs.n_src, n_dst=pairs.n_dst, act=1)
+        y = torch.nn.functional.dropout(y, p, True)
+        ctx.pairs, ctx.scale = pairs, 1.0 / (1.0 - p)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dY):
+        (y,) = ctx.saved_tensors
+        pairs = ctx.pairs
+        dZ = epilogue_backward(dY.contiguous(), y, None, 2, 0.0, ctx.scale)
+        dA = pairs.by_src().spmm(dZ) if ctx.needs_input_grad[0] else None
+        dB = pairs.by_dst().spmm(dZ) if ctx.needs_input_grad[1] else None
+        dbias = dZ.sum(0) if ctx.needs_input_grad[2] else None
+        return dA, dB, dbias, None, None
+
+
+def gather_add_relu_dropout(pairs: EdgePairs, A, B, bias, p: float):
+    """Differentiable ``dropout(relu(A[src] + B[dst] + bias), p)`` in training mode (``0 < p < 1``)."""
+    return _GatherAddReluDropout.apply(A, B, bias, pairs, float(p))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 17
+#define DGMI_ABI_VERSION 18
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -243,11 +243,12 @@ DGMI_API int dgmi_gather_concat_f32(const int32_t* src, const int32_t* dst, int6
  * halves: lin1(cat(a, b)) = a W_a^T + b W_b^T + bias.  Projecting the NODE tables first
  * (two N x F x H GEMMs) and adding the projected rows per edge avoids materialising the E x 2F
  * matrix and the E x 2F x H GEMM altogether.  Same bytes-per-edge shape as the gather-concat:
- * bound by the streaming write of E*4*F bytes.  bias may be NULL.
+ * bound by the streaming write of E*4*F bytes.  bias may be NULL.  act = 1: out = relu(...) — the
+ * decoder's next operation (layers.py:366) in the pass that writes the E x F result; 0: none.
  */
 DGMI_API int dgmi_gather_add_f32(const int32_t* src, const int32_t* dst, int64_t E, const float* A,
                                  int64_t lda, const float* B, int64_t ldb, const float* bias,
-                                 int64_t F, float* out, int64_t ldo, dgmi_stream_t stream);
+                                 int64_t F, float* out, int64_t ldo, int32_t act, dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
  * Backward of the fused output epilogue over n contiguous elements:

@@ -48,10 +48,12 @@ def gather_concat_raw(src, dst, A, B, out=None, n_src=None, n_dst=None):
     return y
 
 
-def gather_add_raw(src, dst, A, B, bias=None, out=None, n_src=None, n_dst=None):
+def gather_add_raw(src, dst, A, B, bias=None, out=None, n_src=None, n_dst=None, act=0):
     y = A.detach()[src.long()] + B.detach()[dst.long()]
     if bias is not None:
         y = y + bias.detach()
+    if act == 1:
+        y = torch.relu(y)
     if out is not None:
         out.copy_(y)
         return out

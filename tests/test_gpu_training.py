@@ -177,3 +177,53 @@ def test_decoder_relu_dropout_backward_in_one_pass(dev):
     # eval mode, short inputs and p = 0 take torch's own path
     assert "ReluDropout" not in type(M._relu_dropout(torch.nn.Dropout(p).eval(), xb).grad_fn).__name__
     assert "ReluDropout" not in type(M._relu_dropout(drop, xb[:100]).grad_fn).__name__
+
+
+def test_decoder_stages_fused_relu_and_one_pass_backward(dev):
+    """The decoder's two stages with the relu inside the producing kernel (gather-add store / GEMM epilogue), torch's
+    dropout, and the backward gated once from the output: same masks (same RNG consumption), first stage bit-equal to
+    the plain composition, the GEMM stage to 1e-6 / 1e-5."""
+    from dream_gnn_amd import model as M, ops
+
+    rng = np.random.default_rng(3)
+    nd, ns, E, Fh, p = 300, 200, M._EdgeLinear.MIN_ROWS + 333, 128, 0.3
+    src = torch.from_numpy(rng.integers(0, nd, E).astype(np.int32)).to(dev)
+    dst = torch.from_numpy(rng.integers(0, ns, E).astype(np.int32)).to(dev)
+    pairs = ops.EdgePairs(src, dst, nd, ns)
+    A0, B0 = torch.randn(nd, Fh, device=dev), torch.randn(ns, Fh, device=dev)
+    b0 = torch.randn(Fh, device=dev)
+    w = torch.randn(E, Fh, device=dev)
+
+    def run(fused):
+        A, B, b = (t.clone().requires_grad_(True) for t in (A0, B0, b0))
+        torch.manual_seed(5)
+        if fused:
+            y = ops.gather_add_relu_dropout(pairs, A, B, b, p)
+        else:
+            y = torch.nn.functional.dropout(torch.relu(ops.gather_add(pairs, A, B, b)), p, True)
+        (y * w).sum().backward()
+        return y.detach(), A.grad, B.grad, b.grad
+
+    for got, want in zip(run(True), run(False)):
+        assert torch.equal(got, want)
+
+    lin = torch.nn.Linear(Fh, 64).to(dev)
+    drop = torch.nn.Dropout(p).train()
+    x0 = torch.randn(E, Fh, device=dev)
+    w2 = torch.randn(E, 64, device=dev)
+
+    def run2(fused):
+        x = x0.clone().requires_grad_(True)
+        lin.zero_grad()
+        torch.manual_seed(6)
+        y = M._edge_linear_relu_dropout(lin, drop, x) if fused else drop(torch.relu(lin(x)))
+        (y * w2).sum().backward()
+        return y.detach(), x.grad, lin.weight.grad.clone(), lin.bias.grad.clone()
+
+    got, want = run2(True), run2(False)
+    assert "EdgeLinearReluDropout" in type(M._edge_linear_relu_dropout(lin, drop, x0.clone().requires_grad_(True)).grad_fn).__name__
+    # the GEMM with a relu epilogue may round the last bit differently: an element within rounding of zero can flip side
+    y_g, y_w = got[0], want[0]
+    assert float((y_g - y_w).abs().max()) <= 1e-5 * float(y_w.abs().max())
+    for g, wv in zip(got[1:], want[1:]):
+        assert float((g - wv).abs().max()) <= 1e-4 * float(wv.abs().max())
