@@ -51,7 +51,10 @@ class _EdgeLinear(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # 1-wide layer: the input gradient is an outer product — a broadcast multiply (25 us), not a K = 1 GEMM (79 us)
+            dx = dy * weight if weight.shape[0] == 1 else dy @ weight
         dw = db = None
         if ctx.needs_input_grad[1] and weight.shape[0] == 1:
             # lin3 (64 -> 1): dy^T x is a weighted column sum; as a batched GEMM its 1-wide tiles took 200 us
