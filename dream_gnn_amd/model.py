@@ -31,6 +31,15 @@ class Attention(nn.Module):
         return (beta * z).sum(1), beta
 
 
+def _split_k_weight_grad(dy, x, chunk: int):
+    """``dy^T x`` (out x in) with K = number of rows: chunks of ``chunk`` rows as one batched GEMM, summed, plus the tail."""
+    n = x.shape[0] // chunk * chunk
+    dw = torch.bmm(dy[:n].view(-1, chunk, dy.shape[1]).transpose(1, 2), x[:n].view(-1, chunk, x.shape[1])).sum(0)
+    if n < x.shape[0]:
+        dw = dw + dy[n:].t() @ x[n:]
+    return dw
+
+
 class _EdgeLinear(torch.autograd.Function):
     """``F.linear`` over the decoder's edge list (E rows, a few hundred thousand on the real datasets), with the
     weight gradient ``dY^T X`` (out x in, K = E) evaluated split-K: the library's single GEMM for an (64 x 128 x 467 k)
@@ -60,11 +69,7 @@ class _EdgeLinear(torch.autograd.Function):
             # lin3 (64 -> 1): dy^T x is a weighted column sum; as a batched GEMM its 1-wide tiles took 200 us
             dw = (x * dy).sum(0, keepdim=True)
         elif ctx.needs_input_grad[1]:
-            c = _EdgeLinear.CHUNK
-            n = x.shape[0] // c * c
-            dw = torch.bmm(dy[:n].view(-1, c, dy.shape[1]).transpose(1, 2), x[:n].view(-1, c, x.shape[1])).sum(0)
-            if n < x.shape[0]:
-                dw = dw + dy[n:].t() @ x[n:]
+            dw = _split_k_weight_grad(dy, x, _EdgeLinear.CHUNK)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db
@@ -118,11 +123,7 @@ class _EdgeLinearReluDropout(torch.autograd.Function):
         dx = dz @ weight if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1]:
-            c = _EdgeLinear.CHUNK
-            n = x.shape[0] // c * c
-            dw = torch.bmm(dz[:n].view(-1, c, dz.shape[1]).transpose(1, 2), x[:n].view(-1, c, x.shape[1])).sum(0)
-            if n < x.shape[0]:
-                dw = dw + dz[n:].t() @ x[n:]
+            dw = _split_k_weight_grad(dz, x, _EdgeLinear.CHUNK)
         if ctx.needs_input_grad[2]:
             db = dz.sum(0)
         return dx, dw, db, None
