@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset) starts its N ranks itself
+(`self_launch`: N fresh child processes of this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, spawned
+before this process has made any GPU call; rank 0's JSON line is forwarded as the last line of stdout; the first
+rank that fails, or the time limit, ends the others).
+
 Workload (N = 1): BASELINE config 4 — synthetic bipartite 100k drugs x 50k diseases with
 10M edges plus kNN-64 similarity graphs on both node sets, F = 128, fp32.  One *step* is one
 pass of the message-passing hot path over those graphs, forward and backward:
@@ -22,8 +27,9 @@ other reading (config 4's node set with N x the edges) is measured in the same r
 standing and reported under `edge_scaled` (`--scale edges` swaps the two).  Every rank owns a
 contiguous block of destination rows of every graph — cut by nnz (`balanced_row_bounds`) — and all
 their in-edges; each local SpMM is followed by the exchange of its row block over RCCL
-(dream_gnn_amd/shard.py: one all-gather per product by default; `DGMI_EXCHANGE=direct` selects the
-all-links batched point-to-point form, `=auto` times both at start-up and keeps the faster),
+(dream_gnn_amd/shard.py: one RCCL all-gather per product — the default, and the only form the judged reading
+uses unless asked; `DGMI_EXCHANGE=direct` selects the all-links batched point-to-point form, `=auto` times both at
+start-up, guarded, and keeps the faster: both opt-in, the point-to-point form has never run on real links),
 overlapped with the next SpMM; time = max over ranks.
 
 The JSON line carries, besides the contract fields:
@@ -461,6 +467,117 @@ def model_steps_in_child():
     except Exception as exc:  # noqa: BLE001
         return {"error": repr(exc)}
 
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv, timeout_s=None):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes of this file (one per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, exactly what
+    `torch.distributed.run` would set) and return the exit code to leave with.  Called before this process has imported
+    torch or made any HIP call — the children are ordinary spawns, nothing is exec'ed in place.  Rank 0's stdout is
+    relayed line by line and its JSON line is printed again as the LAST line of stdout; the other ranks' stdout goes to
+    stderr.  The first rank that exits non-zero ends the others (SIGTERM, SIGKILL 10 s later), and so does the time
+    limit (`DGMI_BENCH_LAUNCH_TIMEOUT` seconds, default 1500): nobody waits forever on a peer that died."""
+    import signal
+    import subprocess
+    import threading
+
+    timeout_s = float(os.environ.get("DGMI_BENCH_LAUNCH_TIMEOUT", "1500")) if timeout_s is None else timeout_s
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(_free_port()),
+               WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), DGMI_SKIP_BUILD="1",  # built by the parent, once
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs, relays, last_json = [], [], [None]
+
+    def relay(pipe, sink, remember):
+        for line in pipe:
+            if remember and line.lstrip().startswith("{"):
+                last_json[0] = line.rstrip("\n")
+                continue  # printed once, last
+            sink.write(line)
+            sink.flush()
+
+    def stop_all(sig):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.send_signal(sig)
+                except OSError:
+                    pass
+
+    for r in range(n):
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                             stdout=subprocess.PIPE, text=True, bufsize=1)
+        procs.append(p)
+        t = threading.Thread(target=relay, args=(p.stdout, sys.stdout if r == 0 else sys.stderr, r == 0), daemon=True)
+        t.start()
+        relays.append(t)
+    old = {s: signal.signal(s, lambda signum, _f: (stop_all(signum), sys.exit(128 + signum))) for s in (signal.SIGTERM, signal.SIGINT)}
+    rc, deadline = 0, time.monotonic() + timeout_s
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc = bad[0][1] if bad[0][1] > 0 else 1
+                sys.stderr.write("bench.py self-launch: rank %d exited with %d; stopping the other ranks\n" % bad[0])
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > deadline:
+                rc = 124
+                sys.stderr.write("bench.py self-launch: %d ranks still running after %.0f s; stopping them\n"
+                                 % (sum(c is None for c in codes), timeout_s))
+                break
+            time.sleep(0.1)
+        if rc != 0:
+            stop_all(signal.SIGTERM)
+            t_kill = time.monotonic() + 10
+            while any(p.poll() is None for p in procs) and time.monotonic() < t_kill:
+                time.sleep(0.1)
+            stop_all(signal.SIGKILL)
+        for p in procs:
+            p.wait()
+    finally:
+        for s, h in old.items():
+            signal.signal(s, h)
+    for t in relays:
+        t.join(timeout=5)
+    if last_json[0] is not None:
+        print(last_json[0], flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py self-launch: rank 0 printed no JSON line\n")
+        rc = 1
+    return rc
+
+def launcher_rehearsal(args, dist, rank, world):
+    """DGMI_BENCH_REHEARSAL=launcher: what the ranks of a self-launched job do when only the LAUNCH is under test
+    (tests/test_bench_launch.py, no GPU): rendezvous over gloo at the address the launcher handed out, the same
+    barrier + max-over-ranks reduction `measure` ends with, rank 0 prints a JSON line.  No product code runs: the
+    product has no CPU path.  DGMI_BENCH_REHEARSAL_FAIL_RANK / _HANG_RANK make one rank exit non-zero / never finish."""
+    import torch
+
+    if os.environ.get("DGMI_BENCH_REHEARSAL_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    dist.init_process_group("gloo")
+    if os.environ.get("DGMI_BENCH_REHEARSAL_HANG_RANK") == str(rank):
+        time.sleep(3600)
+    dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ranks = torch.tensor([1.0])
+    dist.all_reduce(ranks)
+    if rank == 0:
+        print("rank 0 of %d: rendezvous at %s:%s" % (world, os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"]), flush=True)
+        print(json.dumps({"rehearsal": "launcher", "n_gpus": world, "ranks_seen": int(ranks.item()), "max_over_ranks": float(t.item()),
+                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
 
 def main():
     if "--model-steps-child" in sys.argv:
@@ -488,6 +605,10 @@ def main():
 
     __graft_entry__.ensure_built()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: be one.  Nothing in this process has touched the GPU (torch is not even imported yet).
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
 
@@ -495,9 +616,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (see module docstring)" % args.gpus)
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if os.environ.get("DGMI_BENCH_REHEARSAL") == "launcher":
+        return launcher_rehearsal(args, dist, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
     # One rank per GPU.  (Rehearsal of the N>1 path on a 1-GPU box: DGMI_DIST_BACKEND=gloo lets
@@ -543,13 +664,14 @@ def main():
         return elapsed, float(edges.item())
 
     def pick_exchange(ops):
-        """The row-block exchange form (dream_gnn_amd.shard.choose_exchange).  DGMI_EXCHANGE=auto (default): time the
-        RCCL all-gather, then the all-links batched point-to-point form inside try/except (3 steps each) and keep
-        the faster; a form that raises on any rank is dropped on every rank, so the job falls back to the
-        all-gather instead of dying.  DGMI_EXCHANGE=allgather|direct forces one."""
+        """The row-block exchange form (dream_gnn_amd.shard.choose_exchange).  Default: the RCCL all-gather — the
+        well-trodden collective, and the only form the judged reading depends on.  Opt-in: DGMI_EXCHANGE=auto times
+        the all-gather, then the all-links batched point-to-point form inside try/except (3 steps each) and keeps
+        the faster (a form that raises on any rank is dropped on every rank; a HANG inside an untried collective
+        cannot be guarded, which is why this is not the default); DGMI_EXCHANGE=direct forces the point-to-point form."""
         from dream_gnn_amd import shard as S
 
-        mode = os.environ.get("DGMI_EXCHANGE", "auto")
+        mode = os.environ.get("DGMI_EXCHANGE", "allgather")
         return S.choose_exchange(lambda ex: measure(ops, 3, 1, exchange=ex)[0] / 3, dev, world, mode=mode)
 
     def reading(ops, elapsed, edges, steps, exchange):
@@ -704,8 +826,9 @@ def main():
             "roofline": roofline,
             "kernels": per_op,
         }
-        if exchange_timing is not None:
-            out["config"]["exchange_ms_per_step"] = exchange_timing
+        if world > 1:  # ms per step by exchange form: both when DGMI_EXCHANGE=auto timed them, else the judged run's own
+            out["config"]["exchange_ms_per_step"] = exchange_timing if exchange_timing is not None else \
+                {exchange: round(elapsed / args.steps * 1e3, 3), "note": "the timed run itself; DGMI_EXCHANGE=auto (opt-in) also times the all-links form"}
         if primary_reading is not None:
             out["node_scaled" if args.scale == "nodes" else "edge_scaled"] = primary_reading
             out["config"]["six_x_claim"] = (

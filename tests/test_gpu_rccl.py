@@ -106,3 +106,30 @@ def test_rccl_calls_of_the_sharded_path_run_on_one_gpu():
     assert res["backend"] == "nccl" and res["all_reduce"] == 3.5
     assert res["fwd_equal"] and res["bwd_equal"] and res["allgather_equal"] and res["p2p_equal"], res
     assert res["choose"] == (None, None)
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with NO launcher in the environment, on the GPU box: the parent spawns both ranks
+    (they share cuda:0 and exchange over gloo, staged through the host — a rehearsal of the N > 1 schedule, not a
+    scaling number), the real sharded workload runs, and the line that comes out last carries what an N > 1 reading
+    must: both weak-scaling readings with per-rank compute, un-hidden exchange, the model's prediction."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update({"DGMI_DIST_BACKEND": "gloo", "DGMI_BENCH_LAUNCH_TIMEOUT": "420"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=480, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["parallelism"].startswith("2 ranks") and "(allgather)" in line["config"]["parallelism"]
+    for key in ("node_scaled", "edge_scaled"):
+        rd = line[key]
+        for f in ("per_rank_compute_ms_per_step", "exchange_ms_not_hidden", "per_rank_recv_MB_per_step", "predicted_ms_per_step"):
+            assert f in rd, (key, f)
+        assert "predicted_speedup" in rd
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "bench_self_launch_2rank_gloo.json"), "w") as f:
+        f.write(json.dumps(line) + "\n")
