@@ -322,21 +322,35 @@ def variants(torch, dev, ops):
     from dream_gnn_amd import graph as G, ops as O, synth
 
     out = {}
-    # (1) the products the TRAINING step runs: edge dropout every iteration (train.py:267), kept
-    # count max(1, int(E * 0.9)) per edge list, applied on the fly (CSRGraph.dropped)
+    # (1) the products the TRAINING step runs: edge dropout every iteration (train.py:267), kept count
+    # max(1, int(E * 0.9)) per edge list.  A dropped view of a graph in the XCD-local form compacts each layout once
+    # (dgmi_compact_layout_i32) and then runs the plain kernels; `on_the_fly_ms` is the round-2/3 form (keep(eid[p]) per
+    # edge, product and pass) for comparison.  A training step uses every layout 3 x (L = 3 layers): `ms_amortised_L3`.
     for op in ops[:2] + ops[4:5]:
         g = op.shard.local
         keep = max(1, int(g.nnz * 0.9))
         desc = O.random_subset_select(g.nnz, keep, 12345, dev)
-        view = g.dropped(desc)
         kept = int(O.keep_mask(desc, g.nnz).sum().item())
         t_sel = timeit(torch, lambda: O.random_subset_select(g.nnz, keep, 12345, dev), reps=10, warm=2)
         ds = None if op.ds is None else op.ds[op.shard.lo:op.shard.hi].contiguous()
+        view = g.dropped(desc)
         t_drop = timeit(torch, lambda: view.spmm(op.X, op.ss, ds, out=op.y_local))
         t_full = timeit(torch, lambda: g.spmm(op.X, op.ss, ds, out=op.y_local))
+        t_compact = timeit(torch, lambda: g.dropped(desc).spmm(op.X, op.ss, ds, out=op.y_local), reps=10, warm=2) - t_drop
+        old = O.COMPACT_DROPPED
+        O.COMPACT_DROPPED = False
+        try:
+            fly = g.dropped(desc)
+            t_fly = timeit(torch, lambda: fly.spmm(op.X, op.ss, ds, out=op.y_local))
+        finally:
+            O.COMPACT_DROPPED = old
         out["edge_dropped " + op.name] = {"kept_edges": kept, "expected_kept": keep, "ms": round(t_drop, 4),
-                                          "undropped_ms": round(t_full, 4), "subset_selection_ms": round(t_sel, 4),
-                                          "gedges_per_s_of_parent": round(g.nnz / t_drop / 1e6, 2)}
+                                          "undropped_ms": round(t_full, 4), "layout_compaction_ms": round(t_compact, 4),
+                                          "ms_amortised_L3": round(t_drop + t_compact / 3, 4),
+                                          "ratio_to_undropped_amortised_L3": round((t_drop + t_compact / 3) / t_full, 3),
+                                          "on_the_fly_ms": round(t_fly, 4), "subset_selection_ms": round(t_sel, 4),
+                                          "gedges_per_s_kept": round(kept / t_drop / 1e6, 2)}
+        del view, fly
     # (2) SURVEY §8(d): the same 10 M edges with Zipf(1.2) destination degrees (longest row ~2 M edges)
     gen = torch.Generator(device=dev).manual_seed(1)
     p = 1.0 / torch.arange(1, BASE_DIS + 1, device=dev, dtype=torch.float64) ** 1.2
@@ -395,6 +409,42 @@ def variants(torch, dev, ops):
                 entry["kNN-4 n=%d (%d nnz) F=%d us" % (n, gk.nnz, width)] = round(timeit(torch, lambda: gk.spmm(x, out=o), reps=50) * 1e3, 2)
         out[cfg] = entry
     return out
+
+
+def edge_dropped_step(torch, dev, ops, layers=3):
+    """The second headline: the step of `run_step` with ALL 8 products edge-dropped, as every training iteration of the
+    reference runs them (train.py:267: augmentation is unconditional; augmentation.py:48-52,114-118: keep
+    max(1, int(0.9 E)) edges per edge list, the forward relation and its reverse drawn independently).  One step =
+    ONE batched subset selection over the 4 edge lists (both directions of the bipartite list + 2 kNN graphs), the
+    compaction of the 8 layouts the products read, the 8 products.  Timed as a whole by HIP events; `edges` counts the
+    KEPT edges the products sum.  `layers` products per layout = what an L-layer model runs per iteration."""
+    from dream_gnn_amd import ops as O
+
+    # which edge list each product's layout belongs to (build_ops: fwd A, fwd B, bwd of A, bwd of B, then fwd / bwd of each kNN graph)
+    lists = [0, 1, 0, 1, 2, 2, 3, 3]
+    Es = [ops[0].nnz, ops[1].nnz, ops[4].nnz, ops[6].nnz]
+    keeps = [max(1, int(e * 0.9)) for e in Es]
+    ds = [None if op.ds is None else op.ds[op.shard.lo:op.shard.hi].contiguous() for op in ops]
+    state = {"seed": 1}
+
+    def step(n_layers):
+        state["seed"] += 1
+        descs = O.random_subset_select_batch(Es, keeps, [state["seed"] * 4 + i for i in range(4)], dev)
+        views = [op.shard.local.dropped(descs[lists[i]:lists[i] + 1]) for i, op in enumerate(ops)]
+        for _ in range(n_layers):
+            for op, v, d in zip(ops, views, ds):
+                v.spmm(op.X, op.ss, d, out=op.y_local)
+
+    kept = float(sum(keeps[lists[i]] for i in range(len(ops))))
+    t1 = timeit(torch, lambda: step(1), reps=20, warm=3)
+    tL = timeit(torch, lambda: step(layers), reps=10, warm=2)
+    return {"what": "run_step with all 8 products edge-dropped (10 % per edge list, a new subset every step): 1 batched "
+                    "selection + 8 layout compactions + 8 products",
+            "kept_edges_per_step": int(kept), "ms_per_step": round(t1, 4), "value": kept / (t1 * 1e-3), "unit": "kept edges/s",
+            "ms_per_step_with_%d_products_per_layout" % layers: round(tL, 4),
+            "value_L%d" % layers: layers * kept / (tL * 1e-3),
+            "note": "a training iteration of an L = %d model reuses each compacted layout %d x; `value_L%d` is the rate of that "
+                    "schedule, `value` pays selection + compaction for ONE product per layout" % (layers, layers, layers)}
 
 
 def model_steps(torch, dev):
@@ -846,6 +896,10 @@ def main():
                 out["variants"] = variants(torch, dev, ops)
             except Exception as exc:  # noqa: BLE001
                 out["variants"] = {"error": repr(exc)}
+            try:
+                out["edge_dropped_step"] = edge_dropped_step(torch, dev, ops)
+            except Exception as exc:  # noqa: BLE001
+                out["edge_dropped_step"] = {"error": repr(exc)}
             out["model_steps"] = model_steps_in_child()
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgmi.so")
 TORCH_LIB_PATH = os.path.join(_HERE, "libdgmi_torch.so")  # the dreamgnn_mi::* dispatcher ops over the C ABI
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 # name -> (restype, argtypes); mirrors include/dgmi.h one to one.
 _vp = ctypes.c_void_p
@@ -63,6 +63,10 @@ SIGNATURES = {
     "dgmi_scale_rows_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "dgmi_weighted_colsum_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, ctypes.c_int32, _vp, _i64, _vp]),
     "dgmi_rank_add_f32": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, ctypes.c_int32, _vp]),
+    "dgmi_compact_layout_workspace_bytes": (ctypes.c_size_t, [_i64]),
+    "dgmi_compact_layout_i32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp,
+                                               ctypes.c_size_t, _vp]),
+    "dgmi_set_tuning": (ctypes.c_int, [ctypes.c_char_p, _i64]),
 }
 
 
@@ -101,6 +105,11 @@ def _load_torch_ops():
 
 
 torch_ops = _load_torch_ops()
+
+
+def set_tuning(name: str, value: int) -> None:
+    """Override one launch parameter of the library (``dgmi_set_tuning``; measurement tools and one test)."""
+    check(lib.dgmi_set_tuning(name.encode(), int(value)), "dgmi_set_tuning(%s)" % name)
 
 
 def check(status: int, what: str) -> None:

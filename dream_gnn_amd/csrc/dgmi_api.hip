@@ -8,6 +8,7 @@
 #include "dgmi.h"
 #include "dgmi_keep.h"
 #include "dgmi_kernels.h"
+#include "dgmi_tuning.h"
 
 namespace {
 
@@ -15,9 +16,48 @@ inline hipStream_t as_stream(dgmi_stream_t s) { return static_cast<hipStream_t>(
 
 inline int from_hip(hipError_t e) { return e == hipSuccess ? DGMI_OK : DGMI_ERR_LAUNCH; }
 
+long long env_ll(const char* name, long long dflt) {
+  const char* e = getenv(name);
+  return e != nullptr && e[0] != '\0' ? atoll(e) : dflt;
+}
+
 }  // namespace
 
+namespace dgmi {
+
+// The environment is read here, once (thread-safe static initialisation), never on a launch path.
+Tuning& tuning() {
+  static Tuning t = [] {
+    Tuning v;
+    v.sliced_rows = (int)env_ll("DGMI_SLICED_ROWS", 0);
+    v.sliced_touch_lead = (int)env_ll("DGMI_SLICED_PF", -1);
+    v.sliced_lpr = (int)env_ll("DGMI_SLICED_LPR", 0);
+    v.sliced_no_off32 = getenv("DGMI_NO_OFF32") != nullptr ? 1 : 0;
+    v.sliced_chunk_rows = env_ll("DGMI_SLICED_CHUNK_ROWS", 0);
+    v.select_window_min = env_ll("DGMI_SELECT_WINDOW_MIN", 0);
+    v.select_narrow_window = env_ll("DGMI_SELECT_NARROW_WINDOW", 0) != 0 ? 1 : 0;
+    return v;
+  }();
+  return t;
+}
+
+}  // namespace dgmi
+
 extern "C" {
+
+DGMI_API int dgmi_set_tuning(const char* name, int64_t value) {
+  if (name == nullptr) return DGMI_ERR_INVALID_ARG;
+  dgmi::Tuning& t = dgmi::tuning();
+  if (strcmp(name, "sliced_rows") == 0) t.sliced_rows = (int)value;
+  else if (strcmp(name, "sliced_touch_lead") == 0) t.sliced_touch_lead = (int)value;
+  else if (strcmp(name, "sliced_lpr") == 0) t.sliced_lpr = (int)value;
+  else if (strcmp(name, "sliced_no_off32") == 0) t.sliced_no_off32 = value != 0;
+  else if (strcmp(name, "sliced_chunk_rows") == 0) t.sliced_chunk_rows = value;
+  else if (strcmp(name, "select_window_min") == 0) t.select_window_min = value;
+  else if (strcmp(name, "select_narrow_window") == 0) t.select_narrow_window = value != 0;
+  else return DGMI_ERR_INVALID_ARG;
+  return DGMI_OK;
+}
 
 DGMI_API int dgmi_abi_version(void) { return DGMI_ABI_VERSION; }
 
@@ -232,8 +272,7 @@ static int64_t sliced_chunk_rows(int64_t n_dst, int32_t n_slices, int64_t F) {
   int64_t rows = ((int64_t)4096 << 20) / (row_bytes > 0 ? row_bytes : 1);  // chunking off by default (measured slower)
   rows = rows / 1024 * 1024;
   if (rows < 1024) rows = 1024;
-  const char* env = getenv("DGMI_SLICED_CHUNK_ROWS");  // tuning aid
-  if (env != nullptr && atoll(env) > 0) rows = atoll(env);
+  if (dgmi::tuning().sliced_chunk_rows > 0) rows = dgmi::tuning().sliced_chunk_rows;  // tuning aid (dgmi_set_tuning)
   return rows < n_dst ? rows : n_dst;
 }
 
@@ -390,6 +429,27 @@ DGMI_API int dgmi_keep_mask_f32(const uint32_t* keep, int32_t n_keep, int64_t E,
   if (E == 0) return DGMI_OK;
   if (mask == nullptr) return DGMI_ERR_INVALID_ARG;
   return from_hip(dgmi::keep_mask_f32(keep, n_keep, E, mask, as_stream(stream)));
+}
+
+DGMI_API size_t dgmi_compact_layout_workspace_bytes(int64_t nnz) {
+  return nnz < 0 ? 0 : dgmi::compact_workspace_bytes(nnz);
+}
+
+DGMI_API int dgmi_compact_layout_i32(const int32_t* ptr, int64_t n_ptr, const int32_t* indices, const float* vals,
+                                     const int32_t* eid, int64_t nnz, const uint32_t* keep, int32_t n_keep, int32_t* ptr_out,
+                                     int32_t* indices_out, float* vals_out, void* workspace, size_t workspace_bytes,
+                                     dgmi_stream_t stream) {
+  if (n_ptr < 0 || nnz < 0 || n_keep < 0 || n_keep > dgmi::kMaxKeepSegs || (n_keep > 0 && keep == nullptr))
+    return DGMI_ERR_INVALID_ARG;
+  if (nnz > INT32_MAX || n_ptr > INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (n_ptr == 0) return DGMI_OK;
+  if (ptr == nullptr || ptr_out == nullptr) return DGMI_ERR_INVALID_ARG;
+  if (nnz > 0 && (indices == nullptr || eid == nullptr || indices_out == nullptr || workspace == nullptr)) return DGMI_ERR_INVALID_ARG;
+  if ((vals == nullptr) != (vals_out == nullptr)) return DGMI_ERR_INVALID_ARG;
+  if (nnz > 0 && workspace_bytes < dgmi::compact_workspace_bytes(nnz)) return DGMI_ERR_WORKSPACE;
+  if (nnz > 0 && (reinterpret_cast<uintptr_t>(workspace) & 7)) return DGMI_ERR_INVALID_ARG;
+  return from_hip(dgmi::compact_layout_i32(ptr, n_ptr, indices, vals, eid, nnz, keep, n_keep, ptr_out, indices_out, vals_out,
+                                           workspace, as_stream(stream)));
 }
 
 DGMI_API int dgmi_gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,

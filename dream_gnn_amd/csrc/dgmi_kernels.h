@@ -191,6 +191,13 @@ hipError_t random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float*
 hipError_t gather_f32(const float* in, const int32_t* perm, int64_t n, float* out,
                       hipStream_t s);
 
+// a CSR-shaped layout (ptr[n_ptr], indices[, vals], eid over nnz positions) with the edges dropped under `keep`
+// removed, stable (dgmi_compact.hip): ptr_out[n_ptr], indices_out / vals_out sized nnz (the survivors fill a prefix)
+size_t compact_workspace_bytes(int64_t nnz);
+hipError_t compact_layout_i32(const int32_t* ptr, int64_t n_ptr, const int32_t* indices, const float* vals, const int32_t* eid,
+                              int64_t nnz, const void* keep, int n_keep, int32_t* ptr_out, int32_t* indices_out, float* vals_out,
+                              void* workspace, hipStream_t s);
+
 // (f4) neighbours of the k largest cosine similarities per row of a normalised (N, D) matrix (dgmi_knn.hip)
 bool knn_supported(int64_t N, int64_t D, int64_t k);
 size_t knn_workspace_bytes(int64_t N, int64_t D, int k);  // small N: partial lists of the candidate splits; large N: the screen's buffers

@@ -20,10 +20,10 @@
 // (seed, E, keep), restated bit for bit by the oracle.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "dgmi_keep.h"
 #include "dgmi_kernels.h"
+#include "dgmi_tuning.h"
 
 namespace dgmi {
 namespace {
@@ -344,8 +344,8 @@ hipError_t random_subset_select_batch(int n, const int64_t* E, const int64_t* ke
                                       const uint64_t* seed_dev) {
   if (n <= 0) return hipSuccess;
   BatchParams p = {};
-  const char* wmin = getenv("DGMI_SELECT_WINDOW_MIN");
-  p.window_min = wmin != nullptr && atoll(wmin) > 0 ? atoll(wmin) : kWindowMinE;
+  const Tuning& tune = tuning();
+  p.window_min = tune.select_window_min > 0 ? tune.select_window_min : kWindowMinE;
   int64_t e_max = 0;  // of the lists that take the window passes
   for (int i = 0; i < n; ++i) {
     p.E[i] = E[i];
@@ -355,8 +355,7 @@ hipError_t random_subset_select_batch(int n, const int64_t* E, const int64_t* ke
     if (E[i] >= p.window_min && keep[i] > 0 && keep[i] < E[i] && E[i] > e_max) e_max = E[i];
   }
   p.seed_dev = seed_dev;
-  const char* narrow = getenv("DGMI_SELECT_NARROW_WINDOW");
-  p.narrow = narrow != nullptr && narrow[0] == '1';
+  p.narrow = tune.select_narrow_window != 0;
   SelectState* st = static_cast<SelectState*>(workspace);
   KeepSeg* out = static_cast<KeepSeg*>(descs);
   const dim3 one(1, (unsigned)n);

@@ -14,10 +14,10 @@
 // nnz * 4F bytes of gather that now come out of L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "dgmi_kernels.h"
 #include "dgmi_segment.h"
+#include "dgmi_tuning.h"
 
 namespace dgmi {
 namespace {
@@ -32,16 +32,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_plane_row(float* p, const float4& v) {
   // one streaming 16-B store: the planes are write-once / read-once; keep them from evicting
   // the XCD's slice of X out of L2
+  // (ordinary stores instead: the step of bench.py 3.03 ms against 2.85 ms, profiles/r03_swept_experiment/)
   v4f t = {v.x, v.y, v.z, v.w};
-#ifdef DGMI_EXPERIMENT_NO_PLANE_STORES  // timing-only build: what the plane stores cost the gather kernel (results wrong)
-  if (v.x == 123456.789f) *reinterpret_cast<v4f*>(p) = t;
-  return;
-#endif
-#ifdef DGMI_PLANES_REGULAR_STORE  // A/B switch: ordinary stores run the step in 3.03 ms instead of 2.85 ms
-  *reinterpret_cast<v4f*>(p) = t;
-#else
   __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
-#endif
 }
 
 // A (row, slice) segment is short (deg / n_slices: 12-25 edges at config 4).  In the slice-major
@@ -181,12 +174,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
         if (dropped) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       // fast path (group-uniform): all 8 edges belong to the current row -> balanced tree, no
-      // per-edge boundary tests
-#ifdef DGMI_EXPERIMENT_ALWAYS_FAST  // timing-only build: every batch on the fast path (results wrong) — the slow path's price
-      if (true) {
-#else
+      // per-edge boundary tests (a timing-only build that took it for EVERY batch gained 2-7 %: the slow path is not
+      // what holds the kernel at 0.81 of the gather probe — profiles/r03_swept_experiment/README.md)
       if (base + j + kUnroll <= next_b) {
-#endif
         if (WEIGHTED) {
 #pragma unroll
           for (int u = 0; u < kUnroll; ++u) {
@@ -302,23 +292,21 @@ hipError_t launch_sliced(const SlicedArgs& a, int64_t row_begin, int64_t row_end
   // products 31.8 / 31.2 / 30.8 / 28.2 / 27.9, full-width ones 28.4 / 29.5 / 30.1 / 30.2 / 30.3, the step 30.8 / 31.0 / 31.0 /
   // 30.1 / 29.7.  One value for every width: where a group's run starts decides how its batches of 8 are cut, so a
   // width-dependent value would make the column passes round differently from the full-width pass (they are bit-identical,
-  // test_xcd_sliced_column_passes).  DGMI_SLICED_ROWS forces a value (tools).
-  const char* rows_env = getenv("DGMI_SLICED_ROWS");
-  const int rows_req = rows_env != nullptr ? atoi(rows_env) : kRowsPerGroup;
+  // test_xcd_sliced_column_passes).  Tuning::sliced_rows forces a value (tools).
+  const Tuning& tune = tuning();
+  const int rows_req = tune.sliced_rows > 0 ? tune.sliced_rows : kRowsPerGroup;
   const int R = rows_req < 1 ? 1 : (rows_req < LPR ? rows_req : LPR - 1);
   const int64_t per_block = (int64_t)kWavesPerBlock * G * R;
   const int64_t blocks = (row_end - row_begin + per_block - 1) / per_block;
   dim3 block(kWave * kWavesPerBlock);
   const int key = (a.vals ? 4 : 0) | (a.src_scale ? 2 : 0) | (a.n_keep > 0 ? 1 : 0);
-  const bool no_off32 = getenv("DGMI_NO_OFF32") != nullptr;  // A/B switch (tools; read per call so one process can flip it)
-  const bool off32 = !no_off32 && (a.n_src * a.ldx + a.F) * 4 < ((int64_t)1 << 32);
+  const bool off32 = !tune.sliced_no_off32 && (a.n_src * a.ldx + a.F) * 4 < ((int64_t)1 << 32);
   // Touch-ahead (see the kernel): one toucher per kTouchGroup worker blocks, kTouchLead worker blocks ahead.  An XCD starts
   // ~7 blocks of its slice per us, so 24 blocks are ~3.5 us of lead — a memory latency, and short enough for the touched
   // lines to still be in its L2.  Step of bench.py: no touching 2.724 ms; wave 0 of every block touching for the block 16 /
   // 24 / 32 further on 2.553 / 2.548 / 2.548; toucher blocks, one per 4 / 8 / 16 workers 2.526 / 2.528 / 2.530
-  // (profiles/r03_touch_ahead/).  DGMI_SLICED_PF overrides the lead (tools/cold_ids_probe.py; 0 = no touchers).
-  const char* pf_env = getenv("DGMI_SLICED_PF");
-  const int touch_lead = pf_env != nullptr ? atoi(pf_env) : kTouchLead;
+  // (profiles/r03_touch_ahead/).  Tuning::sliced_touch_lead overrides the lead (tools/cold_ids_probe.py; 0 = no touchers).
+  const int touch_lead = tune.sliced_touch_lead >= 0 ? tune.sliced_touch_lead : kTouchLead;
   const int touch_group = touch_lead > 0 ? kTouchGroup : 0;
   const int64_t touchers = touch_group > 0 ? (blocks + touch_group - 1) / touch_group : 0;
   dim3 grid((unsigned)((blocks + touchers) * a.n_slices), (unsigned)((a.F + 4 * LPR - 1) / (4 * LPR)));
@@ -376,9 +364,8 @@ hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s) {
     // Half-width groups also mean half as many waves per pass (n_dst / 4 at F = 128): with few, long rows the
     // launch no longer fills the chip (config-5 edge-scaled shard, 6250 rows of 1600 edges: 0.382 -> 0.440 ms),
     // so the rule needs kColumnPassMinRows destination rows.
-    // DGMI_SLICED_LPR forces a width (tools).
-    const char* lpr_env = getenv("DGMI_SLICED_LPR");  // read per call: tools flip it inside one process
-    const int forced_lpr = lpr_env != nullptr ? atoi(lpr_env) : 0;
+    // Tuning::sliced_lpr forces a width (tools).
+    const int forced_lpr = tuning().sliced_lpr;
     int lpr = pick_lpr(a.F);
     if (lpr >= 32 && !a.full_width && a.n_keep == 0 && a.n_dst >= kColumnPassMinRows) {
       const int64_t width = 16 * (int64_t)lpr < 4 * a.F ? 16 * (int64_t)lpr : 4 * a.F;

@@ -487,6 +487,29 @@ Tensor keep_mask(const Tensor& keep, int64_t E) {
   return mask;
 }
 
+// (D3) the layout with the edges dropped under `keep` removed: (ptr_out, indices_out[, vals_out]); indices_out / vals_out
+// keep the parent's length (the survivors fill a prefix: nothing is read back to size them)
+std::tuple<Tensor, Tensor, Tensor> compact_layout(const Tensor& ptr, const Tensor& indices, const OptTensor& vals, const Tensor& eid,
+                                                  const Tensor& keep) {
+  check(ptr, at::kInt, 1, "ptr", ptr);
+  check(indices, at::kInt, 1, "indices", ptr);
+  const int64_t nnz = indices.numel();
+  check_opt(vals, at::kFloat, nnz, "vals", ptr);
+  const Keep k = keep_of(eid, keep, nnz, ptr);
+  TORCH_CHECK(k.n > 0, "compact_layout needs at least one subset description");
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(ptr.device());
+  Tensor ptr_out = at::empty_like(ptr), indices_out = at::empty_like(indices);
+  const bool has_vals = vals.has_value() && vals->defined();
+  Tensor vals_out = has_vals ? at::empty_like(*vals) : Tensor();
+  const size_t wbytes = dgmi_compact_layout_workspace_bytes(nnz);
+  Tensor ws = scratch(ptr, wbytes < 256 ? 256 : wbytes, kBuilder);
+  check_status(dgmi_compact_layout_i32(ptr.data_ptr<int32_t>(), ptr.numel(), indices.data_ptr<int32_t>(), (const float*)optptr(vals),
+                                       k.eid, nnz, k.table, k.n, ptr_out.data_ptr<int32_t>(), indices_out.data_ptr<int32_t>(),
+                                       has_vals ? vals_out.data_ptr<float>() : nullptr, ws.data_ptr(), (size_t)ws.numel(),
+                                       stream_of(ptr)), "dgmi_compact_layout_i32");
+  return {ptr_out, indices_out, has_vals ? vals_out : at::empty({0}, ptr.options().dtype(at::kFloat))};
+}
+
 Tensor spmm_csr_new(const Tensor& indptr, const Tensor& indices, const OptTensor& vals, const OptTensor& eid, const OptTensor& keep,
                     const Tensor& X, const OptTensor& ss, const OptTensor& ds, const OptTensor& plan, int64_t chunk,
                     int64_t act, double slope, const OptTensor& out_mask, double mask_scale) {
@@ -591,6 +614,7 @@ TORCH_LIBRARY(dreamgnn_mi, m) {
   m.def("random_subset_select_batch(Tensor like, int[] E, int[] keep, int[] seed, int[] e_offset) -> Tensor");
   m.def("random_subset_select_batch_dseed(Tensor seeds, int[] E, int[] keep, int[] e_offset) -> Tensor");
   m.def("keep_mask(Tensor keep, int E) -> Tensor");
+  m.def("compact_layout(Tensor ptr, Tensor indices, Tensor? vals, Tensor eid, Tensor keep) -> (Tensor, Tensor, Tensor)");
 }
 
 // ROCm builds of torch dispatch HIP tensors under the CUDA key
@@ -616,6 +640,7 @@ TORCH_LIBRARY_IMPL(dreamgnn_mi, CUDA, m) {
   m.impl("random_subset_select_batch", random_subset_select_batch);
   m.impl("random_subset_select_batch_dseed", random_subset_select_batch_dseed);
   m.impl("keep_mask", keep_mask);
+  m.impl("compact_layout", compact_layout);
 }
 
 TORCH_LIBRARY_IMPL(dreamgnn_mi, Autograd, m) { m.impl("spmm_csr", spmm_csr_autograd); }

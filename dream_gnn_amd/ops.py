@@ -207,6 +207,19 @@ class SlicedCSR:
         self.vals = None
         return self
 
+    def compacted(self, keep, vals=None) -> "SlicedCSR":
+        """This layout with the edges dropped under the subset description(s) ``keep`` REMOVED
+        (``dgmi_compact_layout_i32``: four streaming launches, no sort; survivors keep their order, so it is the layout
+        a rebuild from the kept edge list would give — the reference's per-iteration construction, train.py:267 ->
+        augmentation.py:48-65).  ``vals``: this layout's edge values (sliced order), compacted alongside.  The result
+        runs the plain kernels: no ``eid`` stream, no hash per edge and pass, column passes as usual."""
+        c = SlicedCSR.__new__(SlicedCSR)
+        c.n_dst, c.n_src, c.n_slices = self.n_dst, self.n_src, self.n_slices
+        c.segptr, c.indices, v = _T.compact_layout(self.segptr, self.indices, vals, self.eid, _prep_keep(keep))
+        c.vals = None if vals is None else v
+        c.eid, c.range_flag = None, self.range_flag  # positions no longer map to the caller's edge order
+        return c
+
     _DEFAULT = object()
 
     def _prescale_pays(self, table_bytes: int, one_pass: bool) -> bool:
@@ -272,6 +285,11 @@ SLICED_TIERS = ((48, 420_000_000), (96, 800_000_000), (192, 1_500_000_000))     
 SLICED_LOW_DEGREE = (32, 20_000_000, 80_000_000)                                    # degree >=, table bytes in [lo, hi]
 SPLIT_MIN_TABLE_BYTES = 4_000_000
 PRESCALE_MIN_TABLE_BYTES = 8_000_000  # XCD-local products on tables from this size scale X in a pass of its own
+# Edge-dropped views of graphs that take the XCD-local form: the layout is COMPACTED once per view (a training step
+# makes one view per edge list and runs each layout 3 x forward and 3 x backward) instead of evaluating keep(eid[p])
+# per edge, product and column pass.  Config 4, ms per product un-dropped / dropped on the fly / dropped after
+# compaction: see bench.py `variants`.  DGMI_COMPACT_DROPPED=0 keeps the on-the-fly kernels (A/B, tests).
+COMPACT_DROPPED = os.environ.get("DGMI_COMPACT_DROPPED", "1") != "0"
 SPLIT_TIERS = ((48, 600_000_000), (96, 1_000_000_000), (192, 1_800_000_000))
 
 
@@ -323,8 +341,13 @@ class _SplitSliced:
         self.c_plan = build_plan(self.c_indptr, self.n_virtual)
         self.n_rows = n_rows
 
-    def spmm(self, X, src_scale, dst_scale, out, vals, keep=None, epi=None):
-        yv = self.sliced.spmm(X, src_scale, None, None, vals=vals, keep=keep)
+    def spmm(self, X, src_scale, dst_scale, out, vals, keep=None, epi=None, compacted=None):
+        """``compacted``: the virtual-row layout with a view's dropped edges already removed (then ``vals`` / ``keep``
+        are not consulted: it carries its own values)."""
+        if compacted is not None:
+            yv = compacted.spmm(X, src_scale, None, None)
+        else:
+            yv = self.sliced.spmm(X, src_scale, None, None, vals=vals, keep=keep)
         F = yv.shape[1]
         if out is None:
             out = torch.empty((self.n_rows, F), dtype=torch.float32, device=yv.device)
@@ -379,8 +402,10 @@ class CSRGraph:
     def _set_values(self, coo_vals, keep=None):
         self._coo_vals = coo_vals
         self._v = {}  # layout name -> values permuted into that layout
+        self._c = {}  # layout name -> that layout with this view's dropped edges removed (SlicedCSR.compacted)
         self._keep = keep  # (n, 8) int32 subset descriptions applied on the fly, or None
         self._mask = None  # 0/1 keep mask already multiplied into the values by masked(), COO order
+        self._vals_before_mask = None  # the values masked() multiplied its mask into (undropped() restores them)
 
     def with_values(self, coo_vals: Optional[torch.Tensor]) -> "CSRGraph":
         """A view sharing this graph's structure (and whatever it builds later) with other per-edge
@@ -398,8 +423,7 @@ class CSRGraph:
         view = self.with_values(keep if self._coo_vals is None else self._coo_vals * keep)
         view._keep = self._keep
         view._mask = keep if self._mask is None else self._mask * keep
-        view.__dict__["_vals_before_mask"] = self.__dict__.get("_vals_before_mask", self._coo_vals) if self._mask is not None \
-            else self._coo_vals
+        view._vals_before_mask = self._vals_before_mask if self._mask is not None else self._coo_vals
         return view
 
     def dropped(self, desc: torch.Tensor) -> "CSRGraph":
@@ -417,7 +441,8 @@ class CSRGraph:
         view = object.__new__(CSRGraph)
         view._S = self._S
         view._coo_vals, view._v = self._coo_vals, self._v  # values (and their per-layout copies) are shared
-        view._mask = self._mask
+        view._c = {}  # another set of survivors: its own compacted layouts
+        view._mask, view._vals_before_mask = self._mask, self._vals_before_mask
         view._keep = desc if self._keep is None else torch.cat([self._keep, desc])
         if view._keep.shape[0] > 8:
             raise RuntimeError("at most 8 subset descriptions per graph view")
@@ -442,9 +467,19 @@ class CSRGraph:
         view._S = self._S
         vals = self._coo_vals
         if self._mask is not None:
-            vals = self.__dict__.get("_vals_before_mask")
+            vals = self._vals_before_mask
         view._set_values(vals)
         return view
+
+    def _compacted(self, name: str, sliced: "SlicedCSR") -> Optional["SlicedCSR"]:
+        """The XCD-sliced layout ``name`` with this view's dropped edges removed, made on first use and kept with the
+        view (None when the view drops nothing or compaction is switched off)."""
+        if self._keep is None or not COMPACT_DROPPED:
+            return None
+        c = self._c.get(name)
+        if c is None:
+            c = self._c[name] = sliced.compacted(self._keep, self._vals_for(name, sliced.eid))
+        return c
 
     def _vals_for(self, layout: str, eid: torch.Tensor):
         if self._coo_vals is None:
@@ -563,13 +598,18 @@ class CSRGraph:
         if X.dim() == 2 and self._use_sliced(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
             if S.sliced is None:
                 S.sliced = SlicedCSR.from_csr(S.indptr, S.indices, S.eid, S.n_dst, S.n_src)  # one partition pass, no sort
+            c = self._compacted("sliced", S.sliced)
+            if c is not None:
+                return c.spmm(X, src_scale, dst_scale, out, epi=epi)
             return S.sliced.spmm(X, src_scale, dst_scale, out, vals=self._vals_for("sliced", S.sliced.eid), keep=self._keep,
                                  epi=epi)
         if X.dim() == 2 and self._use_split(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
             if S.split is None:
                 S.split = _SplitSliced(S.indptr, S.eid, S.src, S.n_dst, S.n_src)
+            c = self._compacted("split", S.split.sliced)
             return S.split.spmm(X, _prep_scale(src_scale, S.n_src, "src_scale"), _prep_scale(dst_scale, S.n_dst, "dst_scale"),
-                                out, self._vals_for("split", S.split.sliced.eid), keep=self._keep, epi=epi)
+                                out, None if c is not None else self._vals_for("split", S.split.sliced.eid), keep=self._keep,
+                                epi=epi, compacted=c)
         return self._run(S.indptr, S.indices, self.vals, self._plan_if_needed(S.plan, S.max_deg), S.n_dst, S.n_src, X,
                          src_scale, dst_scale, out, S.eid, epi)
 
@@ -584,13 +624,18 @@ class CSRGraph:
         if dY.dim() == 2 and self._use_sliced(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):
             if S.sliced_t is None:
                 S.sliced_t = SlicedCSR.from_csr(indptr_t, indices_t, eid_t, S.n_src, S.n_dst)
+            c = self._compacted("sliced_t", S.sliced_t)
+            if c is not None:
+                return c.spmm(dY, dst_scale, src_scale, out)
             return S.sliced_t.spmm(dY, dst_scale, src_scale, out, vals=self._vals_for("sliced_t", S.sliced_t.eid),
                                    keep=self._keep)
         if dY.dim() == 2 and self._use_split(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):
             if S.split_t is None:
                 S.split_t = _SplitSliced(indptr_t, eid_t, S.dst, S.n_src, S.n_dst)
+            c = self._compacted("split_t", S.split_t.sliced)
             return S.split_t.spmm(dY, _prep_scale(dst_scale, S.n_dst, "dst_scale"), _prep_scale(src_scale, S.n_src, "src_scale"),
-                                  out, self._vals_for("split_t", S.split_t.sliced.eid), keep=self._keep)
+                                  out, None if c is not None else self._vals_for("split_t", S.split_t.sliced.eid), keep=self._keep,
+                                  compacted=c)
         return self._run(indptr_t, indices_t, self._vals_for("csr_t", eid_t), self._plan_if_needed(plan_t, S.max_deg_t), S.n_src, S.n_dst, dY,
                          dst_scale, src_scale, out, eid_t)
 

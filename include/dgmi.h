@@ -19,7 +19,10 @@
  *     `void*` holding a hipStream_t (NULL = the null stream).
  *   - every pointer is a DEVICE pointer on the current HIP device unless the
  *     parameter says "host".  All buffers are caller-owned; the library keeps
- *     no state between calls and allocates nothing.
+ *     no state between calls and allocates nothing.  (One exception, for the
+ *     measurement tools: the launch-parameter overrides of dgmi_set_tuning, which
+ *     are also the only thing the library ever reads from the environment — once,
+ *     not per launch.)
  *   - calls are asynchronous on `stream`, re-entrant, and never synchronise.
  *   - return value: DGMI_OK (0) or a negative dgmi_status; nothing throws,
  *     nothing aborts.  Shapes are validated on the host before any launch;
@@ -38,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 18
+#define DGMI_ABI_VERSION 19
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -336,6 +339,25 @@ DGMI_API int dgmi_random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed,
                                          dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
+ * (D3 / f1) The per-iteration graph rebuild of the reference (train.py:267 -> augmentation.py:48-65: a new
+ * heterograph from the kept edges; :114-124: a new sparse COO) for one layout, without a sort: a CSR-shaped layout
+ * of the PARENT graph — `ptr` (n_ptr entries: indptr of a CSR, or segptr of an XCD-sliced CSR), `indices`, optional
+ * `vals`, `eid`, nnz positions — is copied with the edges dropped under the n_keep subset descriptions removed
+ * (position p survives iff keep(eid[p]), as in the SpMM entry points).  Stable: survivors keep their order, so the
+ * result is bit-identical to the same layout built from the kept edge list.  ptr_out has n_ptr entries;
+ * indices_out / vals_out are sized nnz and the ptr_out[n_ptr - 1] survivors fill their prefix (nothing is read
+ * back).  Four streaming launches, ~12 B per edge (+ 8 with values); the products that follow run the plain
+ * kernels over the compacted layout (n_keep = 0): no eid stream, no hash per edge and pass — at 10 M edges an
+ * edge-dropped product costs 19-27 % more than the un-dropped one on the fly, and less than it after compaction.
+ * workspace: dgmi_compact_layout_workspace_bytes(nnz) bytes, 8-B aligned.  vals and vals_out: both or neither.
+ */
+DGMI_API size_t dgmi_compact_layout_workspace_bytes(int64_t nnz);
+DGMI_API int dgmi_compact_layout_i32(const int32_t* ptr, int64_t n_ptr, const int32_t* indices, const float* vals,
+                                     const int32_t* eid, int64_t nnz, const uint32_t* keep, int32_t n_keep,
+                                     int32_t* ptr_out, int32_t* indices_out, float* vals_out, void* workspace,
+                                     size_t workspace_bytes, dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
  * (f4) Cosine-similarity kNN: nbr[i, 0..k) = the k rows j with the largest <Xn[i], Xn[j]> (self
  * included, as the reference's argpartition includes it), in descending order; Xn is (N, D) fp32 with
  * L2-normalised rows and leading dimension ld.  Replaces the dense N x N similarity matrix plus
@@ -369,6 +391,17 @@ DGMI_API int dgmi_knn_cosine_topk_f32(const float* Xn, int64_t ld, int64_t N, in
 DGMI_API int dgmi_probe_row_gather_f32(const float* table, int64_t n_rows, int64_t F, int64_t groups,
                                        int64_t per_group, int64_t window, int32_t per_xcd, float* out,
                                        dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
+ * Launch-parameter overrides for the measurement tools (the scripts under tools/; not part of the product path).  The built-in
+ * choices are measured ones; a tool that wants to A/B one inside a single process sets it here.
+ * Names: "sliced_rows", "sliced_touch_lead" (-1 = built-in, 0 = no touch-ahead), "sliced_lpr", "sliced_no_off32",
+ * "sliced_chunk_rows", "select_window_min", "select_narrow_window"; 0 restores the built-in choice (-1 for
+ * sliced_touch_lead).  The same values are read from the environment variables DGMI_SLICED_ROWS, DGMI_SLICED_PF,
+ * DGMI_SLICED_LPR, DGMI_NO_OFF32, DGMI_SLICED_CHUNK_ROWS, DGMI_SELECT_WINDOW_MIN, DGMI_SELECT_NARROW_WINDOW ONCE, when
+ * the library first needs them; no launch reads the environment.  Not thread-safe against concurrent launches.
+ */
+DGMI_API int dgmi_set_tuning(const char* name /* host */, int64_t value);
 
 #ifdef __cplusplus
 }

@@ -300,6 +300,17 @@ def keep_mask(desc, E):
     return mask
 
 
+def compact_layout(ptr, indices, vals, eid, desc):
+    """Restatement of ``dgmi_compact_layout_i32``: a CSR-shaped layout of the parent graph with the edges dropped
+    under the description(s) ``desc`` removed, stable — i.e. the same layout of the graph the reference REBUILDS from
+    the kept edges each iteration (augmentation.py:48-65 ``dgl.heterograph`` of ``src[keep], dst[keep]``; :114-124
+    for a sparse COO).  Returns (ptr_out, indices_out, vals_out): only the survivors, not padded."""
+    ptr, indices, eid = np.asarray(ptr, np.int64), np.asarray(indices), np.asarray(eid, np.int64)
+    kept = keep_mask(desc, int(eid.max()) + 1 if eid.size else 0)[eid].astype(bool) if eid.size else np.zeros(0, bool)
+    rank = np.concatenate([[0], np.cumsum(kept)])
+    return rank[ptr].astype(np.int32), indices[kept], None if vals is None else np.asarray(vals)[kept]
+
+
 def edge_dropout_keep(num_edges, dropout_rate, perm):
     """Kept edge positions of random_edge_dropout(_sparse): the first
     max(1, int(E*(1-p))) entries of a permutation (augmentation.py:48-52,114-118)."""

@@ -16,7 +16,7 @@ def _declared():
 
 
 def test_header_declares_the_expected_entry_points():
-    assert _declared() == ["dgmi_abi_version", "dgmi_csr_from_coo_i32", "dgmi_csr_sliced_from_coo_i32", "dgmi_csr_sliced_from_csr_i32",
+    assert _declared() == ["dgmi_abi_version", "dgmi_compact_layout_i32", "dgmi_compact_layout_workspace_bytes", "dgmi_csr_from_coo_i32", "dgmi_csr_sliced_from_coo_i32", "dgmi_csr_sliced_from_csr_i32",
                            "dgmi_device_ok", "dgmi_epilogue_backward_f32", "dgmi_gather_add_f32", "dgmi_gather_concat_f32",
                            "dgmi_gather_f32", "dgmi_keep_mask_f32", "dgmi_knn_cosine_supported", "dgmi_knn_cosine_topk_f32",
                            "dgmi_knn_cosine_workspace_bytes",
@@ -24,7 +24,7 @@ def test_header_declares_the_expected_entry_points():
                            "dgmi_random_subset_mask_f32", "dgmi_random_subset_select", "dgmi_random_subset_select_batch",
                            "dgmi_random_subset_select_batch_dseed",
                            "dgmi_random_subset_workspace_bytes", "dgmi_rank_add_f32", "dgmi_scale_rows_f32",
-                           "dgmi_spmm_csr_f32", "dgmi_spmm_csr_planned_f32", "dgmi_spmm_default_chunk",
+                           "dgmi_set_tuning", "dgmi_spmm_csr_f32", "dgmi_spmm_csr_planned_f32", "dgmi_spmm_default_chunk",
                            "dgmi_spmm_partials_bytes", "dgmi_spmm_plan_build", "dgmi_spmm_plan_bytes",
                            "dgmi_spmm_sliced_f32", "dgmi_spmm_sliced_planes_bytes", "dgmi_status_string", "dgmi_weighted_colsum_f32"]
 
@@ -71,6 +71,15 @@ def test_argument_validation_returns_codes_without_a_gpu():
     assert L.dgmi_random_subset_select(10, 5, 0, 2 ** 31 - 5, 16, 16, 1 << 20, None) == -2                # offset + E overflows
     assert L.dgmi_keep_mask_f32(None, 1, 5, 16, None) == -1 and L.dgmi_keep_mask_f32(None, 0, 0, None, None) == 0
     assert L.dgmi_probe_row_gather_f32(16, 8, 6, 8, 8, 8, 0, 16, None) == -1                              # F % 4
+    # per-step layout compaction: size query is host arithmetic; argument errors come back before any launch
+    assert L.dgmi_compact_layout_workspace_bytes(0) >= 0 and L.dgmi_compact_layout_workspace_bytes(10_000_000) < 4 << 20
+    assert L.dgmi_compact_layout_i32(16, 5, 16, None, 16, 100, None, 1, 16, 16, None, 16, 1 << 20, None) == -1  # keep missing
+    assert L.dgmi_compact_layout_i32(16, 5, 16, 16, 16, 100, 16, 1, 16, 16, None, 16, 1 << 20, None) == -1      # vals without vals_out
+    assert L.dgmi_compact_layout_i32(16, 5, 16, None, 16, 100, 16, 1, 16, 16, None, 16, 8, None) == -3          # workspace too small
+    assert L.dgmi_compact_layout_i32(None, 0, None, None, None, 0, None, 0, None, None, None, None, 0, None) == 0
+    # launch-parameter overrides: known names only; the library reads no environment on a launch path
+    assert L.dgmi_set_tuning(b"sliced_rows", 0) == 0 and L.dgmi_set_tuning(b"no_such_knob", 1) == -1
+    assert L.dgmi_set_tuning(None, 1) == -1
     # plan sizing is host arithmetic: items <= n_rows + nnz/chunk, long rows <= nnz/(chunk+1)
     assert L.dgmi_spmm_default_chunk(50_000, 10_000_000) == 512
     assert L.dgmi_spmm_default_chunk(681, 465_000) == 128
@@ -178,3 +187,16 @@ def test_integration_md_stub_matches_the_header_signatures():
         got = list(getattr(ns["lib"], n).argtypes)
         assert [ctypes.sizeof(a) for a in got] == [ctypes.sizeof(a) for a in args], n
         assert getattr(ns["lib"], n).restype is res or ctypes.sizeof(getattr(ns["lib"], n).restype) == ctypes.sizeof(res), n
+
+
+def test_no_launch_path_reads_the_environment():
+    """the environment is read once (dgmi_api.hip `tuning()`, the kNN crossovers' static
+    initialisers), never per launch; the product kernels carry no experiment switches."""
+    csrc = os.path.join(ROOT, "dream_gnn_amd", "csrc")
+    for name in ("dgmi_sliced.hip", "dgmi_select.hip", "dgmi_spmm.hip", "dgmi_plan.hip", "dgmi_compact.hip", "dgmi_csr.hip",
+                 "dgmi_sort.hip", "dgmi_edge.hip"):
+        text = open(os.path.join(csrc, name)).read()
+        assert "getenv" not in text, name
+        assert "DGMI_EXPERIMENT" not in text and "#ifdef" not in text, name
+    api = open(os.path.join(csrc, "dgmi_api.hip")).read()
+    assert api.count("getenv") == 2 and "static Tuning t" in api  # env_ll + the presence test, both inside tuning()

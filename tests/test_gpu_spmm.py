@@ -623,16 +623,21 @@ def test_edge_dropout_on_the_fly_every_kernel(oracle, dev, F, weighted):
     assert np.all(np.abs(x.grad.cpu().numpy() - ref_t) <= RTOL * bound_t + 1e-30)
 
 
-def test_subset_selection_window_miss_is_taken_over_exactly(oracle, dev, monkeypatch):
+def test_subset_selection_window_miss_is_taken_over_exactly(oracle, dev):
     """Long lists find the threshold inside an 8-sigma window of the hash space; if the window ever misses,
     one workgroup selects the list on its own.  With the window narrowed to ~2 edges it (almost) always
     misses: the description is still the oracle's, bit for bit."""
     from dream_gnn_amd import ops
 
-    monkeypatch.setenv("DGMI_SELECT_NARROW_WINDOW", "1")
-    for E, keep, seed in ((1_500_000, 1_350_000, 3), (2_000_000, 1_000_000, 2 ** 63 + 5), (1_200_000, 7, 11)):
-        d = ops.random_subset_select(E, keep, seed, dev)
-        assert np.array_equal(d.cpu().numpy(), oracle.random_subset_select(E, keep, seed, 0))
+    from dream_gnn_amd import _lib
+
+    _lib.set_tuning("select_narrow_window", 1)  # (the library reads no environment on a launch path)
+    try:
+        for E, keep, seed in ((1_500_000, 1_350_000, 3), (2_000_000, 1_000_000, 2 ** 63 + 5), (1_200_000, 7, 11)):
+            d = ops.random_subset_select(E, keep, seed, dev)
+            assert np.array_equal(d.cpu().numpy(), oracle.random_subset_select(E, keep, seed, 0))
+    finally:
+        _lib.set_tuning("select_narrow_window", 0)
 
 
 def test_batched_subset_selection_equals_single_calls(oracle, dev):
@@ -805,3 +810,116 @@ def test_compaction_invert_and_nested_descriptions_randomized(oracle, dev):
             y = ops.spmm_csr_raw(g.indptr, g.indices, g.vals, t(X), t(ss), t(ds), plan=plan, eid=g.eid, keep=keep_t)
             err = np.abs(y.cpu().numpy().astype(np.float64) - ref)
             assert np.all(err <= RTOL * bound + 1e-30), (case, "planned" if plan is not None else "wave-per-row", F, E, keep1)
+
+
+@pytest.mark.parametrize("shape", [(300, 2500, 6000), (1, 5, 1), (40, 30, 0), (7, 9, 2047), (7, 9, 2048), (7, 9, 2049),
+                                   (2000, 100, 70000), (50, 4000, 131072), (3, 3, 64), (9000, 500, 40000)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_compacted_layout_is_the_layout_of_the_kept_edge_list(oracle, dev, shape, weighted):
+    """(r4) `dgmi_compact_layout_i32`: the per-step replacement for the reference's graph rebuild (augmentation.py:48-65)
+    at scale.  CSR and XCD-sliced layouts (8 and 3 slices) of the parent, compacted under plain, inverted and nested
+    descriptions, are BIT-IDENTICAL to the same layouts built from the kept edge list — pointers, ids and values
+    (tile edges 2047 / 2048 / 2049, keep = 0, keep = E, empty rows, an empty graph)."""
+    from dream_gnn_amd import _lib, ops
+
+    n_dst, n_src, E = shape
+    rng = np.random.default_rng(E + weighted)
+    dst = rng.integers(0, n_dst, E).astype(np.int32)
+    src = rng.integers(0, n_src, E).astype(np.int32)
+    if E > 100:
+        dst[dst == 1] = 0  # an empty row
+    vals = rng.standard_normal(E).astype(np.float32) if weighted else None
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    tables = []
+    for keep_n, inv in ((int(E * 0.9), 0), (0, 0), (E, 0), (E // 3, 1)):
+        d = oracle.random_subset_select(E, keep_n, 40 + keep_n, 0).copy()
+        d[6] = inv
+        tables.append(np.stack([d]))
+    tables.append(np.stack([oracle.random_subset_select(E, int(E * 0.8), 1, 0), oracle.random_subset_select(E, int(E * 0.5), 2, 0)]))
+    if E > 10:  # a description that covers only a window of the edge ids (relation-fused layouts)
+        tables.append(np.stack([oracle.random_subset_select(E // 2, E // 4, 3, E // 4)]))
+    for table in tables:
+        mask = oracle.keep_mask(table, E).astype(bool)
+        nk = int(mask.sum())
+        keep_t = t(table)
+        # plain CSR
+        ip, ix, ei = oracle.csr_from_coo(dst, src, n_dst)
+        v_csr = None if vals is None else vals[ei]
+        want_ptr, want_ix, want_v = oracle.compact_layout(ip, ix, v_csr, ei, table)
+        kp, ki, _ = oracle.csr_from_coo(dst[mask], src[mask], n_dst)  # the reference's construction
+        assert np.array_equal(want_ptr, kp) and np.array_equal(want_ix, ki)
+        ptr_o, idx_o, v_o = _lib.torch_ops.compact_layout(t(ip), t(ix), t(v_csr), t(ei), keep_t)
+        assert np.array_equal(ptr_o.cpu().numpy(), kp)
+        assert np.array_equal(idx_o.cpu().numpy()[:nk], ki)
+        if weighted:
+            assert np.array_equal(v_o.cpu().numpy()[:nk], want_v)
+        # XCD-sliced
+        for n_slices in (8, 3):
+            sl = ops.SlicedCSR(t(dst), t(src), n_dst, n_src, vals=t(vals), n_slices=n_slices)
+            c = sl.compacted(keep_t, sl.vals)
+            sp, si, se = oracle.csr_sliced_from_coo(dst[mask], src[mask], n_dst, n_src, n_slices)
+            assert np.array_equal(c.segptr.cpu().numpy(), sp), (n_slices, nk)
+            assert np.array_equal(c.indices.cpu().numpy()[:nk], si)
+            if weighted:
+                assert np.array_equal(c.vals.cpu().numpy()[:nk], vals[mask][se])
+
+
+@pytest.mark.parametrize("F", [128, 64, 256])
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("compact", [True, False])
+def test_edge_dropped_view_of_a_sliced_graph_compacted_or_on_the_fly(oracle, dev, monkeypatch, F, weighted, compact):
+    """A dropped view of a graph that takes the XCD-local form: with compaction (default) and with the on-the-fly
+    KEEP kernels (DGMI_COMPACT_DROPPED=0) the product, its transpose and autograd equal the product over a CSR rebuilt
+    from the kept edges; Inf / NaN in source rows that only dropped edges touch never reach the output; the
+    compacted layouts are made once per view and layout."""
+    from dream_gnn_amd import ops
+
+    monkeypatch.setattr(ops, "FORCE_KERNEL", "sliced")
+    monkeypatch.setattr(ops, "COMPACT_DROPPED", compact)
+    rng = np.random.default_rng(F + 2 * weighted)
+    n_dst, n_src, E = 700, 9000, 30000
+    dst = rng.integers(0, n_dst, E).astype(np.int32)
+    src = rng.integers(0, n_src, E).astype(np.int32)
+    vals = rng.standard_normal(E).astype(np.float32) if weighted else None
+    keep_n = max(1, int(E * 0.7))
+    mask = oracle.random_subset_mask(E, keep_n, 77).astype(bool)
+    dead = np.flatnonzero((np.bincount(src, minlength=n_src) > 0) & (np.bincount(src[mask], minlength=n_src) == 0))
+    assert dead.size > 50
+    X = rng.standard_normal((n_src, F)).astype(np.float32)
+    X_bad = X.copy()
+    X_bad[dead[:25]] = np.inf
+    X_bad[dead[25:50]] = np.nan
+    ss = rng.uniform(0.5, 1.5, n_src).astype(np.float32)
+    ds = rng.uniform(0.5, 1.5, n_dst).astype(np.float32)
+    ip, ix, e0 = oracle.csr_from_coo(dst[mask], src[mask], n_dst)
+    v0 = None if vals is None else vals[mask][e0]
+    ref = oracle.spmm_csr(ip, ix, v0, X, ss, ds, acc="f64")
+    bound = oracle.spmm_csr(ip, ix, v0, X, ss, ds, acc="abs")
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    g = ops.CSRGraph(t(dst), t(src), n_dst, n_src, vals=t(vals))
+    view = g.dropped(ops.random_subset_select(E, keep_n, 77, dev))
+    y = view.spmm(t(X_bad), t(ss), t(ds)).cpu().numpy()
+    assert np.isfinite(y).all() and np.all(np.abs(y - ref) <= RTOL * bound + 1e-30)
+    assert ("sliced" in view._c) == compact
+    first = view._c.get("sliced")
+    assert np.array_equal(view.spmm(t(X_bad), t(ss), t(ds)).cpu().numpy(), y) and view._c.get("sliced") is first
+    W = rng.standard_normal((n_dst, F)).astype(np.float32)
+    tp, ti, te = oracle.csr_from_coo(src[mask], dst[mask], n_src)
+    vt = None if vals is None else vals[mask][te]
+    ref_t = oracle.spmm_csr(tp, ti, vt, W, ds, ss, acc="f64")
+    bound_t = oracle.spmm_csr(tp, ti, vt, W, ds, ss, acc="abs")
+    dx = view.spmm_t(t(W), t(ss), t(ds)).cpu().numpy()
+    assert np.all(np.abs(dx - ref_t) <= RTOL * bound_t + 1e-30) and np.all(dx[dead] == 0)
+    x = t(X).requires_grad_(True)
+    ops.spmm_csr(view, x, t(ss), t(ds)).backward(t(W))
+    assert np.all(np.abs(x.grad.cpu().numpy() - ref_t) <= RTOL * bound_t + 1e-30)
+    # the un-dropped parent is untouched by its views
+    ip_f, ix_f, e_f = oracle.csr_from_coo(dst, src, n_dst)
+    ref_f = oracle.spmm_csr(ip_f, ix_f, None if vals is None else vals[e_f], X, ss, ds, acc="f64")
+    assert np.abs(g.spmm(t(X), t(ss), t(ds)).cpu().numpy() - ref_f).max() <= RTOL * np.abs(ref_f).max()
+    # a second dropout on the view (descriptions ANDed): its own compacted layout
+    mask2 = mask & oracle.random_subset_mask(E, E // 2, 5).astype(bool)
+    view2 = view.dropped(ops.random_subset_select(E, E // 2, 5, dev))
+    ip2, ix2, e2 = oracle.csr_from_coo(dst[mask2], src[mask2], n_dst)
+    ref2 = oracle.spmm_csr(ip2, ix2, None if vals is None else vals[mask2][e2], X, ss, ds, acc="f64")
+    assert np.abs(view2.spmm(t(X), t(ss), t(ds)).cpu().numpy() - ref2).max() <= RTOL * max(np.abs(ref2).max(), 1e-30)

@@ -126,3 +126,23 @@ def test_edge_dropout_keep_count_and_subset(E, rate, seed):
     assert len(set(idx)) == keep and all(0 <= i < E for i in idx)
     assert torch.equal(child.src, src[child.keep_idx]) and torch.equal(child.dst, dst[child.keep_idx])
     assert float(child.keep_mask().sum()) == keep
+
+
+def test_oracle_compaction_equals_the_rebuild_from_the_kept_edges(oracle):
+    """The oracle's restatement of the per-step layout compaction == the reference's construction: the same layout
+    built from the kept edge list (augmentation.py:48-65), CSR and source-sliced, with nested descriptions."""
+    rng = np.random.default_rng(9)
+    for E, n_dst, n_src in ((0, 4, 3), (1, 1, 1), (500, 17, 40), (5000, 90, 31)):
+        dst = rng.integers(0, n_dst, E).astype(np.int32)
+        src = rng.integers(0, n_src, E).astype(np.int32)
+        vals = rng.standard_normal(E).astype(np.float32)
+        table = np.stack([oracle.random_subset_select(E, int(E * 0.8), 3, 0), oracle.random_subset_select(E, int(E * 0.6), 4, 0)])
+        mask = oracle.keep_mask(table, E).astype(bool)
+        ip, ix, ei = oracle.csr_from_coo(dst, src, n_dst)
+        p, i, v = oracle.compact_layout(ip, ix, vals[ei], ei, table)
+        kp, ki, ke = oracle.csr_from_coo(dst[mask], src[mask], n_dst)
+        assert np.array_equal(p, kp) and np.array_equal(i, ki) and np.array_equal(v, vals[mask][ke])
+        sp, si, se = oracle.csr_sliced_from_coo(dst, src, n_dst, n_src, 8)
+        p, i, v = oracle.compact_layout(sp, si, vals[se], se, table)
+        kp, ki, ke = oracle.csr_sliced_from_coo(dst[mask], src[mask], n_dst, n_src, 8)
+        assert np.array_equal(p, kp) and np.array_equal(i, ki) and np.array_equal(v, vals[mask][ke])

@@ -38,8 +38,10 @@ def med(pre, reps=25):
     return v[len(v) // 2]
 
 
+from dream_gnn_amd import _lib  # launch-parameter overrides: dgmi_set_tuning (the library reads no env per launch)
+
 print("product:", op.name)
-os.environ["DGMI_SLICED_PF"] = "0"
+_lib.set_tuning("sliced_touch_lead", 0)
 print("touch-ahead off:")
 print("  loop of its own                           %.4f ms" % med(lambda: None))
 print("  flushed before every call                 %.4f ms" % med(flush))
@@ -47,7 +49,7 @@ print("  flushed, then ids re-read                 %.4f ms" % med(lambda: (flush
 print("  flushed, then segptr re-read              %.4f ms" % med(lambda: (flush(), touch(sl.segptr))))
 print("  flushed, then ids + segptr re-read        %.4f ms" % med(lambda: (flush(), touch(sl.indices, sl.segptr))))
 print("  flushed, then the table re-read           %.4f ms" % med(lambda: (flush(), touch(op.X))))
-os.environ["DGMI_SLICED_PF"] = "24"
+_lib.set_tuning("sliced_touch_lead", 24)
 print("touch-ahead 24:")
 print("  loop of its own                           %.4f ms" % med(lambda: None))
 print("  flushed before every call                 %.4f ms" % med(flush))
@@ -56,5 +58,5 @@ print("  flushed, then segptr re-read              %.4f ms" % med(lambda: (flush
 print("  flushed, then ids + segptr re-read        %.4f ms" % med(lambda: (flush(), touch(sl.indices, sl.segptr))))
 print("  flushed, then the table re-read           %.4f ms" % med(lambda: (flush(), touch(op.X))))
 for d in (0, 4, 8, 16, 24, 32, 48, 64, 96, 128, 256):
-    os.environ["DGMI_SLICED_PF"] = str(d)
+    _lib.set_tuning("sliced_touch_lead", d)
     print("touch-ahead %3d blocks: loop of its own %.4f ms   flushed before every call %.4f ms" % (d, med(lambda: None), med(flush)), flush=True)

@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import importlib.util
 import torch
 from dream_gnn_amd import ops
+from dream_gnn_amd import _lib  # dgmi_set_tuning
 dev = torch.device("cuda:0")
 def t(fn, reps=50):
     for _ in range(5): fn()
@@ -16,7 +17,7 @@ def t(fn, reps=50):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
 for wmin in ("65536", "1048576"):
-    os.environ["DGMI_SELECT_WINDOW_MIN"] = wmin
+    _lib.set_tuning("select_window_min", int(wmin))
     for name, Es in (("lrssl encoder graph: 4 relations", [464897, 2746, 464897, 2746]), ("lrssl kNN-4 adjacencies", [6825, 6109, 6800, 6100]),
                      ("C+G merged encoder graph", [407080, 4019, 407080, 4019]), ("one 65 535-edge list", [65535]), ("one 65 536-edge list", [65536]),
                      ("config 4: one 10 M-edge list", [10_000_000])):
@@ -35,7 +36,7 @@ opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-5)
 res = {}
 for rnd in range(4):
     for wmin in ("65536", "1048576"):
-        os.environ["DGMI_SELECT_WINDOW_MIN"] = wmin
+        _lib.set_tuning("select_window_min", int(wmin))
         for _ in range(5): H.train_step(net, opt, batch, labels, do_augment=True)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(30): H.train_step(net, opt, batch, labels, do_augment=True)

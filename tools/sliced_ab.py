@@ -29,8 +29,27 @@ def timeit(fns, rounds=15, inner=5):
     return {k: (sorted(v)[len(v) // 2], min(v)) for k, v in ts.items()}
 
 
+_KNOBS = {"DGMI_SLICED_LPR": "sliced_lpr", "DGMI_NO_OFF32": "sliced_no_off32", "DGMI_SLICED_ROWS": "sliced_rows"}
+
+
 def with_env(fn, **env):
+    """Launch-parameter overrides go through dgmi_set_tuning (the library reads its environment once, not per launch);
+    anything else is set in os.environ as before."""
+    from dream_gnn_amd import _lib
+
+    knobs = {_KNOBS[k]: int(v or 0) for k, v in env.items() if k in _KNOBS}
+    env = {k: v for k, v in env.items() if k not in _KNOBS}
+
     def run():
+        for k, v in knobs.items():
+            _lib.set_tuning(k, v)
+        try:
+            return run_env()
+        finally:
+            for k in knobs:
+                _lib.set_tuning(k, 0)
+
+    def run_env():
         old = {k: os.environ.get(k) for k in env}
         for k, v in env.items():
             if v is None:
