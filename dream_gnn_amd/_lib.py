@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgmi.so")
 TORCH_LIB_PATH = os.path.join(_HERE, "libdgmi_torch.so")  # the dreamgnn_mi::* dispatcher ops over the C ABI
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 # name -> (restype, argtypes); mirrors include/dgmi.h one to one.
 _vp = ctypes.c_void_p
@@ -38,7 +38,8 @@ SIGNATURES = {
                                                     ctypes.POINTER(ctypes.c_size_t), _vp]),
     "dgmi_spmm_sliced_planes_bytes": (ctypes.c_size_t, [_i64, ctypes.c_int32, _i64]),
     "dgmi_spmm_sliced_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp, _vp, _vp, _i64, _i64,
-                                            _i64, _i64, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t] + _EPI + [_vp]),
+                                            _i64, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_size_t] + _EPI
+                             + [_vp]),
     "dgmi_knn_cosine_supported": (ctypes.c_int, [_i64, _i64, _i64]),
     "dgmi_knn_cosine_workspace_bytes": (ctypes.c_size_t, [_i64, _i64, ctypes.c_int32]),
     "dgmi_knn_cosine_topk_f32": (ctypes.c_int, [_vp, _i64, _i64, _i64, ctypes.c_int32, _vp, _vp, ctypes.c_size_t, _vp]),
@@ -67,6 +68,7 @@ SIGNATURES = {
     "dgmi_compact_layout_i32": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp,
                                                ctypes.c_size_t, _vp]),
     "dgmi_set_tuning": (ctypes.c_int, [ctypes.c_char_p, _i64]),
+    "dgmi_row_multiplicity_f32": (ctypes.c_int, [_vp, _vp, _i64, _i64, ctypes.c_float, _vp, _vp, _vp, _vp]),
 }
 
 

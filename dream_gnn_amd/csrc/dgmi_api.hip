@@ -287,12 +287,15 @@ DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices,
                                   const int32_t* eid, const uint32_t* keep, int32_t n_keep,
                                   const float* X, int64_t ldx, const float* src_scale,
                                   const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
-                                  int64_t n_src, int64_t F, int32_t n_slices, int32_t column_passes, void* planes,
+                                  int64_t n_src, int64_t F, int32_t n_slices, int32_t column_passes,
+                                  int32_t id_multiplicity, void* planes,
                                   size_t planes_bytes, int32_t act, float act_slope, const float* out_mask,
                                   int64_t ld_mask, float out_mask_scale, dgmi_stream_t stream) {
   if (n_dst < 0 || n_src < 0 || F < 0 || n_slices < 1 || n_slices > 64 || !keep_args_ok(eid, keep, n_keep) ||
-      !epilogue_ok(act, out_mask, ld_mask, F) || column_passes < 0 || column_passes > 1)
+      !epilogue_ok(act, out_mask, ld_mask, F) || column_passes < 0 || column_passes > 1 || id_multiplicity < 0 ||
+      id_multiplicity > 1)
     return DGMI_ERR_INVALID_ARG;
+  if (id_multiplicity == 1 && (vals != nullptr || n_src > (int64_t)dgmi::kMultIdMask + 1)) return DGMI_ERR_INVALID_ARG;
   if (out_mask != nullptr && (ld_mask % 4 != 0 || (reinterpret_cast<uintptr_t>(out_mask) & 15))) return DGMI_ERR_INVALID_ARG;
   if (n_dst >= INT32_MAX || n_src >= INT32_MAX || F > INT32_MAX) return DGMI_ERR_TOO_LARGE;
   if (n_dst == 0 || F == 0) return DGMI_OK;
@@ -306,7 +309,7 @@ DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices,
   if (planes_bytes < dgmi_spmm_sliced_planes_bytes(n_dst, n_slices, F)) return DGMI_ERR_WORKSPACE;
   dgmi::SlicedArgs a{segptr, indices, vals, X, ldx, src_scale, dst_scale, Y, ldy, n_dst, n_src, F, n_slices,
                      static_cast<float*>(planes), F, sliced_chunk_rows(n_dst, n_slices, F), eid, keep, n_keep,
-                     {act, act_slope, out_mask, ld_mask, out_mask_scale}, column_passes == 1};
+                     {act, act_slope, out_mask, ld_mask, out_mask_scale}, column_passes == 1, id_multiplicity == 1};
   return from_hip(dgmi::spmm_sliced_f32(a, as_stream(stream)));
 }
 
@@ -429,6 +432,15 @@ DGMI_API int dgmi_keep_mask_f32(const uint32_t* keep, int32_t n_keep, int64_t E,
   if (E == 0) return DGMI_OK;
   if (mask == nullptr) return DGMI_ERR_INVALID_ARG;
   return from_hip(dgmi::keep_mask_f32(keep, n_keep, E, mask, as_stream(stream)));
+}
+
+DGMI_API int dgmi_row_multiplicity_f32(const int32_t* indptr, const float* vals, int64_t n_rows, int64_t nnz, float rel_tol,
+                                       float* row_scale, int32_t* mult, int32_t* fail, dgmi_stream_t stream) {
+  if (n_rows < 0 || nnz < 0 || !(rel_tol >= 0.f) || fail == nullptr) return DGMI_ERR_INVALID_ARG;
+  if (n_rows >= INT32_MAX || nnz > INT32_MAX) return DGMI_ERR_TOO_LARGE;
+  if (n_rows > 0 && (indptr == nullptr || row_scale == nullptr)) return DGMI_ERR_INVALID_ARG;
+  if (nnz > 0 && (vals == nullptr || mult == nullptr)) return DGMI_ERR_INVALID_ARG;
+  return from_hip(dgmi::row_multiplicity_f32(indptr, vals, n_rows, rel_tol, row_scale, mult, fail, as_stream(stream)));
 }
 
 DGMI_API size_t dgmi_compact_layout_workspace_bytes(int64_t nnz) {

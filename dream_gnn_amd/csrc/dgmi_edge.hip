@@ -325,4 +325,66 @@ hipError_t scale_rows_f32(const float* X, int64_t ldx, const float* scale, int64
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row scale x multiplicity form of a weighted adjacency (one-time, at layout build).  The reference's adjacencies are
+// D^-1 (A + A^T + I) with A a 0/1 kNN matrix (data_loader.py:297-308 `adj + adj.T`, utils.py:11-17 `normalize`): every
+// value of row i is m / rowsum_i with m a small integer.  One wave per row: s = (smallest value) / c for the first
+// c in 1..8 under which every value of the row is m * s, m in 1..8, to within rel_tol (fp32 rounding of m / rowsum);
+// a row with no such form raises *fail and the caller keeps the value stream.
+namespace {
+__global__ __launch_bounds__(256) void row_multiplicity_kernel(const int32_t* __restrict__ indptr, const float* __restrict__ vals,
+                                                               int64_t n_rows, float rel_tol, float* __restrict__ row_scale,
+                                                               int32_t* __restrict__ mult, int32_t* __restrict__ fail) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int b = indptr[row], e = indptr[row + 1];
+  if (e <= b) {
+    if (lane == 0) row_scale[row] = 0.f;
+    return;
+  }
+  float vmin = INFINITY;
+  for (int p = b + lane; p < e; p += 64) vmin = fminf(vmin, vals[p]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) vmin = fminf(vmin, __shfl_xor(vmin, off, 64));
+  float s = 0.f;
+  bool found = false;
+  if (vmin > 0.f && vmin < INFINITY) {
+    for (int c = 1; c <= 8 && !found; ++c) {
+      const float cand = vmin / (float)c;
+      bool ok = true;
+      for (int p = b + lane; p < e; p += 64) {
+        const float v = vals[p];
+        const float m = rintf(v / cand);
+        ok = ok && m >= 1.f && m <= 8.f && fabsf(v - m * cand) <= rel_tol * v;
+      }
+      if (__all(ok)) {  // wave-uniform
+        found = true;
+        s = cand;
+      }
+    }
+  }
+  if (!found) {
+    if (lane == 0) {
+      row_scale[row] = 0.f;
+      atomicOr(fail, 1);
+    }
+    for (int p = b + lane; p < e; p += 64) mult[p] = 0;
+    return;
+  }
+  if (lane == 0) row_scale[row] = s;
+  for (int p = b + lane; p < e; p += 64) mult[p] = (int)rintf(vals[p] / s) - 1;
+}
+}  // namespace
+
+hipError_t row_multiplicity_f32(const int32_t* indptr, const float* vals, int64_t n_rows, float rel_tol, float* row_scale,
+                                int32_t* mult, int32_t* fail, hipStream_t s) {
+  hipError_t err = hipMemsetAsync(fail, 0, sizeof(int32_t), s);
+  if (err != hipSuccess) return err;
+  if (n_rows == 0) return hipSuccess;
+  hipLaunchKernelGGL(row_multiplicity_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, indptr, vals, n_rows, rel_tol,
+                     row_scale, mult, fail);
+  return hipGetLastError();
+}
+
 }  // namespace dgmi

@@ -126,6 +126,12 @@ hipError_t csr_sliced_from_csr_i32(const int32_t* indptr, const int32_t* indices
                                    int32_t* s_indices, int32_t* s_eid, void* workspace, size_t* workspace_bytes,
                                    hipStream_t s);
 
+// Multiplicities carried in the id words of an XCD-sliced layout (SlicedArgs::id_mult): bits 28..30 hold m - 1, bit 31 stays
+// the dropped flag of edge dropout on the fly, ids are < 2^28.
+constexpr int kMultShift = 28;
+constexpr int kMultMax = 7;                  // m - 1 <= 7
+constexpr uint32_t kMultIdMask = 0x0fffffffu;
+
 struct SlicedArgs {
   const int32_t* segptr;   // n_slices * n_dst + 1
   const int32_t* indices;
@@ -146,7 +152,13 @@ struct SlicedArgs {
   int n_keep;
   Epilogue ep;
   bool full_width;         // never split the columns into half-width passes (see spmm_sliced_f32)
+  bool id_mult;            // vals == nullptr and the ids carry integer multiplicities (kMultShift)
 };
+
+// per row of a CSR with positive values: scale s and per-edge m in 1..8 with vals[p] = m * s to within rel_tol, or
+// *fail = 1 when some row has no such form (dgmi_edge.hip); mult[p] = m - 1
+hipError_t row_multiplicity_f32(const int32_t* indptr, const float* vals, int64_t n_rows, float rel_tol, float* row_scale,
+                                int32_t* mult, int32_t* fail, hipStream_t s);
 hipError_t spmm_sliced_f32(const SlicedArgs& a, hipStream_t s);
 
 // out[e] = cat(A[src[e]], B[dst[e]])   (dgmi_edge.hip)

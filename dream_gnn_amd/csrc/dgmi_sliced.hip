@@ -63,7 +63,11 @@ __device__ __forceinline__ float4 ld_row(const float* __restrict__ X, const floa
   return ld4(Xc + (int64_t)idx * ldx);
 }
 
-template <int LPR, bool HAS_VALS, bool HAS_SS, bool KEEP, bool OFF32>
+// VALS: 0 = unit edge values; 1 = vals[p]; 2 = small integer multiplicities carried in the id words themselves (bits
+// kMultShift..30 hold m - 1): the reference's adjacencies are D^-1 (A + A^T + I) (data_loader.py:297-308, utils.py:11-17),
+// i.e. value = row scale x multiplicity — the scale goes where dst_scale / src_scale go, the multiplicity rides with the
+// id: no value stream (4 B / edge), no second cross-lane hand-off per edge.
+template <int LPR, int VALS, bool HAS_SS, bool KEEP, bool OFF32>
 __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel(
     const int32_t* __restrict__ segptr, const int32_t* __restrict__ indices,
     const float* __restrict__ vals, const float* __restrict__ X, int64_t ldx,
@@ -72,7 +76,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
     const KeepSeg* __restrict__ keep, int n_keep, int touch_lead, int rows_per_group, int touch_group) {
   constexpr int G = kWave / LPR;
   const int R = rows_per_group;  // < LPR: a group's row boundaries live one per lane
-  constexpr bool WEIGHTED = HAS_VALS || HAS_SS;
+  constexpr bool HAS_VALS = VALS == 1;
+  constexpr bool MULT = VALS == 2;
+  constexpr bool WEIGHTED = HAS_VALS || HAS_SS || MULT;  // a per-edge factor exists
+  constexpr bool W_LANE = HAS_VALS || HAS_SS;            // ... and travels in a register of its own
+  constexpr int kIdMask = MULT ? (int)kMultIdMask : 0x7fffffff;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int grp = lane / LPR, glane = lane % LPR, gbase = grp * LPR;
@@ -139,9 +147,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
   if (e_begin < e_end) {
     const int q = e_begin + glane < e_end ? e_begin + glane : e_begin;
     nxt_idx = fetch_id<KEEP>(indices, eid, keep, n_keep, q);
-    if (WEIGHTED) {
+    if (W_LANE) {
       nxt_w = HAS_VALS ? vals[q] : 1.f;
-      if (HAS_SS) nxt_w *= src_scale[KEEP ? nxt_idx & 0x7fffffff : nxt_idx];
+      if (HAS_SS) nxt_w *= src_scale[(KEEP || MULT) ? nxt_idx & kIdMask : nxt_idx];
     }
   }
   for (int base = e_begin; base < e_end; base += LPR) {
@@ -152,9 +160,9 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
       const int nb = base + LPR;
       const int q = nb + glane < e_end ? nb + glane : nb;
       nxt_idx = fetch_id<KEEP>(indices, eid, keep, n_keep, q);
-      if (WEIGHTED) {
+      if (W_LANE) {
         nxt_w = HAS_VALS ? vals[q] : 1.f;
-        if (HAS_SS) nxt_w *= src_scale[KEEP ? nxt_idx & 0x7fffffff : nxt_idx];
+        if (HAS_SS) nxt_w *= src_scale[(KEEP || MULT) ? nxt_idx & kIdMask : nxt_idx];
       }
     }
     for (int j = 0; j < n; j += kUnroll) {
@@ -164,11 +172,17 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
       for (int u = 0; u < kUnroll; ++u) {
         const int e = j + u;  // < LPR
         int idx = __shfl(my_idx, gbase + e, kWave);
-        if (WEIGHTED) w[u] = __shfl(my_w, gbase + e, kWave);
+        if (W_LANE) w[u] = __shfl(my_w, gbase + e, kWave);
+        if (MULT) {  // the multiplicity arrived with the id
+          const float m = (float)(((idx >> kMultShift) & kMultMax) + 1);
+          w[u] = W_LANE ? w[u] * m : m;
+        }
         const bool dropped = KEEP && idx < 0;
         if (KEEP) {
-          idx = dropped && last_row >= 0 ? last_row : idx & 0x7fffffff;
+          idx = dropped && last_row >= 0 ? last_row : idx & kIdMask;
           last_row = idx;
+        } else if (MULT) {
+          idx &= kIdMask;
         }
         v[u] = ld_row<OFF32>(X, Xc, idx, ldx, row_bytes, col_bytes);
         if (dropped) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -299,7 +313,7 @@ hipError_t launch_sliced(const SlicedArgs& a, int64_t row_begin, int64_t row_end
   const int64_t per_block = (int64_t)kWavesPerBlock * G * R;
   const int64_t blocks = (row_end - row_begin + per_block - 1) / per_block;
   dim3 block(kWave * kWavesPerBlock);
-  const int key = (a.vals ? 4 : 0) | (a.src_scale ? 2 : 0) | (a.n_keep > 0 ? 1 : 0);
+  const int key = (a.vals ? 4 : (a.id_mult ? 8 : 0)) | (a.src_scale ? 2 : 0) | (a.n_keep > 0 ? 1 : 0);
   const bool off32 = !tune.sliced_no_off32 && (a.n_src * a.ldx + a.F) * 4 < ((int64_t)1 << 32);
   // Touch-ahead (see the kernel): one toucher per kTouchGroup worker blocks, kTouchLead worker blocks ahead.  An XCD starts
   // ~7 blocks of its slice per us, so 24 blocks are ~3.5 us of lead — a memory latency, and short enough for the touched
@@ -324,14 +338,18 @@ hipError_t launch_sliced(const SlicedArgs& a, int64_t row_begin, int64_t row_end
                          touch_lead, R, touch_group);                                                             \
   } while (0)
   switch (key) {
-    case 0: DGMI_LAUNCH(false, false, false); break;
-    case 1: DGMI_LAUNCH(false, false, true); break;
-    case 2: DGMI_LAUNCH(false, true, false); break;
-    case 3: DGMI_LAUNCH(false, true, true); break;
-    case 4: DGMI_LAUNCH(true, false, false); break;
-    case 5: DGMI_LAUNCH(true, false, true); break;
-    case 6: DGMI_LAUNCH(true, true, false); break;
-    default: DGMI_LAUNCH(true, true, true); break;
+    case 0: DGMI_LAUNCH(0, false, false); break;
+    case 1: DGMI_LAUNCH(0, false, true); break;
+    case 2: DGMI_LAUNCH(0, true, false); break;
+    case 3: DGMI_LAUNCH(0, true, true); break;
+    case 4: DGMI_LAUNCH(1, false, false); break;
+    case 5: DGMI_LAUNCH(1, false, true); break;
+    case 6: DGMI_LAUNCH(1, true, false); break;
+    case 7: DGMI_LAUNCH(1, true, true); break;
+    case 8: DGMI_LAUNCH(2, false, false); break;
+    case 9: DGMI_LAUNCH(2, false, true); break;
+    case 10: DGMI_LAUNCH(2, true, false); break;
+    default: DGMI_LAUNCH(2, true, true); break;
   }
 #undef DGMI_LAUNCH
   return hipGetLastError();

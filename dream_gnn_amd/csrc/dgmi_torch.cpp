@@ -279,7 +279,8 @@ Tensor spmm_csr_raw(const Tensor& indptr, const Tensor& indices, const OptTensor
 Tensor spmm_sliced_raw(const Tensor& segptr, const Tensor& indices, const OptTensor& vals, const OptTensor& eid,
                        const OptTensor& keep, const Tensor& X, const OptTensor& src_scale, const OptTensor& dst_scale,
                        int64_t n_dst, int64_t n_slices, const OptTensor& out, int64_t act = 0, double slope = 0.0,
-                       const OptTensor& out_mask = c10::nullopt, double mask_scale = 1.0, int64_t column_passes = 0) {
+                       const OptTensor& out_mask = c10::nullopt, double mask_scale = 1.0, int64_t column_passes = 0,
+                       int64_t id_mult = 0) {
   check(segptr, at::kInt, 1, "segptr", segptr);
   check(indices, at::kInt, 1, "indices", segptr);
   TORCH_CHECK(segptr.numel() == n_slices * n_dst + 1, "segptr has ", segptr.numel(), " entries, expected n_slices * n_dst + 1");
@@ -298,7 +299,8 @@ Tensor spmm_sliced_raw(const Tensor& segptr, const Tensor& indices, const OptTen
   check_status(dgmi_spmm_sliced_f32(segptr.data_ptr<int32_t>(), indices.data_ptr<int32_t>(), (const float*)optptr(vals), k.eid,
                                     k.table, k.n, x.t.data_ptr<float>(), x.ld, (const float*)optptr(src_scale),
                                     (const float*)optptr(dst_scale), y.data_ptr<float>(), x.F, n_dst, x.rows, x.F,
-                                    (int32_t)n_slices, (int32_t)column_passes, planes.data_ptr(), pbytes, e.act, e.slope, e.mask,
+                                    (int32_t)n_slices, (int32_t)column_passes, (int32_t)id_mult, planes.data_ptr(), pbytes, e.act,
+                                    e.slope, e.mask,
                                     e.ldm, e.mscale, stream_of(segptr)), "dgmi_spmm_sliced_f32");
   return y;
 }
@@ -510,6 +512,19 @@ std::tuple<Tensor, Tensor, Tensor> compact_layout(const Tensor& ptr, const Tenso
   return {ptr_out, indices_out, has_vals ? vals_out : at::empty({0}, ptr.options().dtype(at::kFloat))};
 }
 
+// (D2) row scale x multiplicity form of a weighted CSR: (row_scale[n_rows], mult[nnz] = m - 1, fail[1])
+std::tuple<Tensor, Tensor, Tensor> row_multiplicity(const Tensor& indptr, const Tensor& vals, double rel_tol) {
+  check(indptr, at::kInt, 1, "indptr", indptr);
+  check(vals, at::kFloat, 1, "vals", indptr);
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(indptr.device());
+  const int64_t n_rows = indptr.numel() - 1, nnz = vals.numel();
+  Tensor scale = at::empty({n_rows}, vals.options()), mult = at::empty({nnz}, indptr.options()), fail = at::empty({1}, indptr.options());
+  check_status(dgmi_row_multiplicity_f32(indptr.data_ptr<int32_t>(), vals.data_ptr<float>(), n_rows, nnz, (float)rel_tol,
+                                         scale.data_ptr<float>(), mult.data_ptr<int32_t>(), fail.data_ptr<int32_t>(), stream_of(indptr)),
+               "dgmi_row_multiplicity_f32");
+  return {scale, mult, fail};
+}
+
 Tensor spmm_csr_new(const Tensor& indptr, const Tensor& indices, const OptTensor& vals, const OptTensor& eid, const OptTensor& keep,
                     const Tensor& X, const OptTensor& ss, const OptTensor& ds, const OptTensor& plan, int64_t chunk,
                     int64_t act, double slope, const OptTensor& out_mask, double mask_scale) {
@@ -523,16 +538,16 @@ void spmm_csr_out(const Tensor& indptr, const Tensor& indices, const OptTensor& 
 Tensor spmm_sliced_new(const Tensor& segptr, const Tensor& indices, const OptTensor& vals, const OptTensor& eid,
                        const OptTensor& keep, const Tensor& X, const OptTensor& ss, const OptTensor& ds, int64_t n_dst,
                        int64_t n_slices, int64_t act, double slope, const OptTensor& out_mask, double mask_scale,
-                       int64_t column_passes) {
+                       int64_t column_passes, int64_t id_mult) {
   return spmm_sliced_raw(segptr, indices, vals, eid, keep, X, ss, ds, n_dst, n_slices, c10::nullopt, act, slope, out_mask,
-                         mask_scale, column_passes);
+                         mask_scale, column_passes, id_mult);
 }
 void spmm_sliced_out(const Tensor& segptr, const Tensor& indices, const OptTensor& vals, const OptTensor& eid,
                      const OptTensor& keep, const Tensor& X, const OptTensor& ss, const OptTensor& ds, int64_t n_dst,
                      int64_t n_slices, Tensor out, int64_t act, double slope, const OptTensor& out_mask, double mask_scale,
-                     int64_t column_passes) {
+                     int64_t column_passes, int64_t id_mult) {
   spmm_sliced_raw(segptr, indices, vals, eid, keep, X, ss, ds, n_dst, n_slices, out, act, slope, out_mask, mask_scale,
-                  column_passes);
+                  column_passes, id_mult);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -598,10 +613,10 @@ TORCH_LIBRARY(dreamgnn_mi, m) {
         "float mask_scale=1.) -> ()");
   m.def("spmm_sliced_raw(Tensor segptr, Tensor indices, Tensor? vals, Tensor? eid, Tensor? keep, Tensor X, Tensor? src_scale, "
         "Tensor? dst_scale, int n_dst, int n_slices, int act=0, float slope=0., Tensor? out_mask=None, float mask_scale=1., "
-        "int column_passes=0) -> Tensor");
+        "int column_passes=0, int id_mult=0) -> Tensor");
   m.def("spmm_sliced_out(Tensor segptr, Tensor indices, Tensor? vals, Tensor? eid, Tensor? keep, Tensor X, Tensor? src_scale, "
         "Tensor? dst_scale, int n_dst, int n_slices, Tensor(a!) out, int act=0, float slope=0., Tensor? out_mask=None, "
-        "float mask_scale=1., int column_passes=0) -> ()");
+        "float mask_scale=1., int column_passes=0, int id_mult=0) -> ()");
   m.def("epilogue_backward(Tensor dY, Tensor Y, Tensor? mask, int act, float slope, float mask_scale) -> Tensor");
   m.def("knn_cosine_topk(Tensor Xn, int k) -> Tensor");
   m.def("scale_rows(Tensor X, Tensor scale) -> Tensor");
@@ -614,6 +629,7 @@ TORCH_LIBRARY(dreamgnn_mi, m) {
   m.def("random_subset_select_batch(Tensor like, int[] E, int[] keep, int[] seed, int[] e_offset) -> Tensor");
   m.def("random_subset_select_batch_dseed(Tensor seeds, int[] E, int[] keep, int[] e_offset) -> Tensor");
   m.def("keep_mask(Tensor keep, int E) -> Tensor");
+  m.def("row_multiplicity(Tensor indptr, Tensor vals, float rel_tol) -> (Tensor, Tensor, Tensor)");
   m.def("compact_layout(Tensor ptr, Tensor indices, Tensor? vals, Tensor eid, Tensor keep) -> (Tensor, Tensor, Tensor)");
 }
 
@@ -640,6 +656,7 @@ TORCH_LIBRARY_IMPL(dreamgnn_mi, CUDA, m) {
   m.impl("random_subset_select_batch", random_subset_select_batch);
   m.impl("random_subset_select_batch_dseed", random_subset_select_batch_dseed);
   m.impl("keep_mask", keep_mask);
+  m.impl("row_multiplicity", row_multiplicity);
   m.impl("compact_layout", compact_layout);
 }
 

@@ -195,6 +195,7 @@ class SlicedCSR:
         self.segptr, self.indices, self.eid, self.range_flag = _T.csr_sliced_from_coo(dst, src, self.n_dst, self.n_src,
                                                                                     self.n_slices)
         self.vals = None if vals is None else gather_f32(vals, self.eid)
+        self.id_mult = False  # True: the id words carry integer multiplicities (bits 28..30 = m - 1), no value stream
 
     @classmethod
     def from_csr(cls, indptr, indices, eid, n_dst, n_src, n_slices: int = N_SLICES):
@@ -205,18 +206,22 @@ class SlicedCSR:
         self.segptr, self.indices, self.eid, self.range_flag = _T.csr_sliced_from_csr(indptr, indices, eid, self.n_src,
                                                                                     self.n_slices)
         self.vals = None
+        self.id_mult = False
         return self
 
-    def compacted(self, keep, vals=None) -> "SlicedCSR":
+    def compacted(self, keep, vals=None, indices=None, id_mult=False) -> "SlicedCSR":
         """This layout with the edges dropped under the subset description(s) ``keep`` REMOVED
         (``dgmi_compact_layout_i32``: four streaming launches, no sort; survivors keep their order, so it is the layout
         a rebuild from the kept edge list would give — the reference's per-iteration construction, train.py:267 ->
-        augmentation.py:48-65).  ``vals``: this layout's edge values (sliced order), compacted alongside.  The result
-        runs the plain kernels: no ``eid`` stream, no hash per edge and pass, column passes as usual."""
+        augmentation.py:48-65).  ``vals``: this layout's edge values (sliced order), compacted alongside; ``indices``
+        (with ``id_mult``): id words to compact instead of the layout's own — the same ids carrying multiplicities.  The
+        result runs the plain kernels: no ``eid`` stream, no hash per edge and pass, column passes as usual."""
         c = SlicedCSR.__new__(SlicedCSR)
         c.n_dst, c.n_src, c.n_slices = self.n_dst, self.n_src, self.n_slices
-        c.segptr, c.indices, v = _T.compact_layout(self.segptr, self.indices, vals, self.eid, _prep_keep(keep))
+        c.segptr, c.indices, v = _T.compact_layout(self.segptr, self.indices if indices is None else indices, vals, self.eid,
+                                                   _prep_keep(keep))
         c.vals = None if vals is None else v
+        c.id_mult = bool(id_mult)
         c.eid, c.range_flag = None, self.range_flag  # positions no longer map to the caller's edge order
         return c
 
@@ -231,8 +236,10 @@ class SlicedCSR:
         passes = 1 if one_pass or self.n_dst < 32768 or table_bytes // self.n_slices <= (4 << 20) else 2  # the launcher's column-pass rule
         return table_bytes <= 6 * int(self.indices.shape[0]) * passes
 
-    def spmm(self, X, src_scale=None, dst_scale=None, out=None, vals=_DEFAULT, keep=None, epi=None, full_width=False):
-        """``vals`` (in sliced order, see ``eid``) overrides the values given at construction;
+    def spmm(self, X, src_scale=None, dst_scale=None, out=None, vals=_DEFAULT, keep=None, epi=None, full_width=False,
+             indices=None, id_mult=None):
+        """``vals`` (in sliced order, see ``eid``) overrides the values given at construction; ``indices`` with
+        ``id_mult=True``: id words carrying integer edge multiplicities (bits 28..30 = m - 1; then ``vals`` must be None);
         ``keep``: subset descriptions applied through ``eid`` (edge dropout on the fly); ``epi``: output
         epilogue (act, slope, out_mask, mask_scale) applied by the plane-reduce kernel; ``full_width``:
         never sweep the columns in two half-width passes (``column_passes = 1`` of the C ABI)."""
@@ -248,14 +255,15 @@ class SlicedCSR:
             # including the pass)
             X = _T.scale_rows(X, src_scale.reshape(-1).contiguous())
             src_scale = None
-        args = (self.segptr, self.indices, vals, self.eid if keep is not None else None,
+        id_mult = self.id_mult if id_mult is None else bool(id_mult)
+        args = (self.segptr, self.indices if indices is None else indices, vals, self.eid if keep is not None else None,
                 None if keep is None else _prep_keep(keep), X, None if src_scale is None else src_scale.reshape(-1),
                 None if dst_scale is None else dst_scale.reshape(-1), self.n_dst, self.n_slices)
         epi = epi or _NO_EPI
         passes = 1 if full_width else 0
         if out is None:
-            return _T.spmm_sliced_raw(*args, *epi, passes)
-        _T.spmm_sliced_out(*args, out, *epi, passes)
+            return _T.spmm_sliced_raw(*args, *epi, passes, int(id_mult))
+        _T.spmm_sliced_out(*args, out, *epi, passes, int(id_mult))
         return out
 
 
@@ -290,6 +298,14 @@ PRESCALE_MIN_TABLE_BYTES = 8_000_000  # XCD-local products on tables from this s
 # per edge, product and column pass.  Config 4, ms per product un-dropped / dropped on the fly / dropped after
 # compaction: see bench.py `variants`.  DGMI_COMPACT_DROPPED=0 keeps the on-the-fly kernels (A/B, tests).
 COMPACT_DROPPED = os.environ.get("DGMI_COMPACT_DROPPED", "1") != "0"
+# Weighted graphs in the XCD-local form whose values are `row scale x small integer` — every adjacency the reference
+# builds: D^-1 (A + A^T + I), data_loader.py:297-308 + utils.py:11-17 — run without a value stream: the multiplicity rides
+# in the id word's spare bits, the row scale goes where dst_scale (forward) / src_scale (transpose) go.  Found once per
+# weighted graph by `dgmi_row_multiplicity_f32` (one host readback, never inside a stream capture); values that have no
+# such form to within 2 ulp keep the value stream.  DGMI_MULT_FORM=0 switches it off (A/B, tests).
+MULT_FORM = os.environ.get("DGMI_MULT_FORM", "1") != "0"
+MULT_REL_TOL = 2.4e-7
+MULT_SHIFT, MULT_MAX_IDS = 28, 1 << 28
 SPLIT_TIERS = ((48, 600_000_000), (96, 1_000_000_000), (192, 1_800_000_000))
 
 
@@ -471,15 +487,51 @@ class CSRGraph:
         view._set_values(vals)
         return view
 
-    def _compacted(self, name: str, sliced: "SlicedCSR") -> Optional["SlicedCSR"]:
+    def _compacted(self, name: str, sliced: "SlicedCSR", mult=None) -> Optional["SlicedCSR"]:
         """The XCD-sliced layout ``name`` with this view's dropped edges removed, made on first use and kept with the
-        view (None when the view drops nothing or compaction is switched off)."""
+        view (None when the view drops nothing or compaction is switched off).  ``mult``: the (row scale, id words)
+        of :meth:`_mult_ids` — then the id words with their multiplicities are what is compacted, and no values."""
         if self._keep is None or not COMPACT_DROPPED:
             return None
         c = self._c.get(name)
         if c is None:
-            c = self._c[name] = sliced.compacted(self._keep, self._vals_for(name, sliced.eid))
+            if mult is not None:
+                c = sliced.compacted(self._keep, None, indices=mult[1], id_mult=True)
+            else:
+                c = sliced.compacted(self._keep, self._vals_for(name, sliced.eid))
+            self._c[name] = c
         return c
+
+    def _mult_form(self):
+        """``(row_scale[n_dst], code_coo[nnz])`` when this view's edge values are ``row_scale[dst] * m``, ``m`` an
+        integer in 1..8 (``code = m - 1``, COO order) — the reference's ``normalize(adj + adj.T + I)`` adjacencies — else
+        None.  Decided once per weighted graph (shared by its dropped views): one kernel + one host readback."""
+        if self._coo_vals is None or not MULT_FORM or self._S.n_src > MULT_MAX_IDS or self._S.n_dst > MULT_MAX_IDS:
+            return None
+        m = self._v.get("mult")
+        if m is None:
+            if torch.cuda.is_current_stream_capturing():
+                return None  # the decision needs a readback: not inside a capture (the value stream is always right)
+            S = self._S
+            scale, code, fail = _T.row_multiplicity(S.indptr, self.vals, MULT_REL_TOL)
+            if int(fail.item()) != 0:
+                m = False
+            else:
+                code_coo = torch.empty_like(code)
+                code_coo[S.eid.long()] = code
+                m = (scale, code_coo)
+            self._v["mult"] = m
+        return m or None
+
+    def _mult_ids(self, name: str, sliced: "SlicedCSR"):
+        """``(row_scale, id words of layout `name` with the multiplicities in bits 28..30)`` or None."""
+        mf = self._mult_form()
+        if mf is None:
+            return None
+        ids = self._v.get(name + "/ids")
+        if ids is None:
+            ids = self._v[name + "/ids"] = sliced.indices | (mf[1][sliced.eid.long()] << MULT_SHIFT)
+        return mf[0], ids
 
     def _vals_for(self, layout: str, eid: torch.Tensor):
         if self._coo_vals is None:
@@ -598,9 +650,14 @@ class CSRGraph:
         if X.dim() == 2 and self._use_sliced(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
             if S.sliced is None:
                 S.sliced = SlicedCSR.from_csr(S.indptr, S.indices, S.eid, S.n_dst, S.n_src)  # one partition pass, no sort
-            c = self._compacted("sliced", S.sliced)
+            mult = self._mult_ids("sliced", S.sliced)
+            if mult is not None:  # values = row scale x multiplicity: the scale is a destination scale here
+                dst_scale = mult[0] if dst_scale is None else mult[0] * dst_scale.reshape(-1)
+            c = self._compacted("sliced", S.sliced, mult)
             if c is not None:
                 return c.spmm(X, src_scale, dst_scale, out, epi=epi)
+            if mult is not None:
+                return S.sliced.spmm(X, src_scale, dst_scale, out, vals=None, keep=self._keep, epi=epi, indices=mult[1], id_mult=True)
             return S.sliced.spmm(X, src_scale, dst_scale, out, vals=self._vals_for("sliced", S.sliced.eid), keep=self._keep,
                                  epi=epi)
         if X.dim() == 2 and self._use_split(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
@@ -624,9 +681,14 @@ class CSRGraph:
         if dY.dim() == 2 and self._use_sliced(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):
             if S.sliced_t is None:
                 S.sliced_t = SlicedCSR.from_csr(indptr_t, indices_t, eid_t, S.n_src, S.n_dst)
-            c = self._compacted("sliced_t", S.sliced_t)
+            mult = self._mult_ids("sliced_t", S.sliced_t)
+            if mult is not None:  # A^T = M^T diag(row scale): the scale multiplies the gathered (destination-node) rows
+                dst_scale = mult[0] if dst_scale is None else mult[0] * dst_scale.reshape(-1)
+            c = self._compacted("sliced_t", S.sliced_t, mult)
             if c is not None:
                 return c.spmm(dY, dst_scale, src_scale, out)
+            if mult is not None:
+                return S.sliced_t.spmm(dY, dst_scale, src_scale, out, vals=None, keep=self._keep, indices=mult[1], id_mult=True)
             return S.sliced_t.spmm(dY, dst_scale, src_scale, out, vals=self._vals_for("sliced_t", S.sliced_t.eid),
                                    keep=self._keep)
         if dY.dim() == 2 and self._use_split(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):

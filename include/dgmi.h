@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DGMI_ABI_VERSION 19
+#define DGMI_ABI_VERSION 20
 
 /* exported-symbol marker (the library is built with -fvisibility=hidden) */
 #if defined(__GNUC__)
@@ -202,6 +202,13 @@ DGMI_API int dgmi_gather_f32(const float* in, const int32_t* perm, int64_t n, fl
  *                                  in two half-width passes (half the footprint each; +4-10 % on
  *                                  regular graphs); 1 = always one full-width pass (graphs whose time
  *                                  is set by a few very long rows: every pass repeats their chain)
+ *                                  id_multiplicity: 0 = `indices` are plain source ids; 1 (vals must be NULL, n_src <=
+ *                                  2^28) = bits 28..30 of every id word hold m - 1 for an integer edge multiplicity
+ *                                  m in 1..8 and the edge contributes m * X[id & 0x0fffffff]: the reference's
+ *                                  adjacencies are D^-1 (A + A^T + I) (data_loader.py:297-308, utils.py:11-17) — value =
+ *                                  row scale x multiplicity; with the scale passed as dst_scale (forward) or folded
+ *                                  into src_scale (transpose) the 4 B / edge value stream disappears
+ *                                  (dgmi_row_multiplicity_f32 finds that form or says there is none).
  */
 DGMI_API int dgmi_csr_sliced_from_coo_i32(const int32_t* row, const int32_t* col, int64_t E,
                                           int64_t n_rows, int64_t n_cols, int32_t n_slices,
@@ -221,7 +228,7 @@ DGMI_API int dgmi_spmm_sliced_f32(const int32_t* segptr, const int32_t* indices,
                                   const float* X, int64_t ldx, const float* src_scale,
                                   const float* dst_scale, float* Y, int64_t ldy, int64_t n_dst,
                                   int64_t n_src, int64_t F, int32_t n_slices, int32_t column_passes,
-                                  void* planes, size_t planes_bytes, int32_t act, float act_slope,
+                                  int32_t id_multiplicity, void* planes, size_t planes_bytes, int32_t act, float act_slope,
                                   const float* out_mask, int64_t ld_mask, float out_mask_scale,
                                   dgmi_stream_t stream);
 
@@ -337,6 +344,16 @@ DGMI_API int dgmi_keep_mask_f32(const uint32_t* keep, int32_t n_keep, int64_t E,
 DGMI_API int dgmi_random_subset_mask_f32(int64_t E, int64_t keep, uint64_t seed, float* mask,
                                          void* workspace, size_t workspace_bytes,
                                          dgmi_stream_t stream);
+
+/* -------------------------------------------------------------------------
+ * (D2) Row scale x multiplicity form of a weighted adjacency, found once when its layouts are built.  For a CSR with
+ * positive values (CSR order): row_scale[r] = s_r and mult[p] = m_p - 1 with vals[p] = m_p * s_r to within rel_tol
+ * (relative; the fp32 rounding of m / rowsum: 2.4e-7 = 2 ulp), m_p in 1..8 — what `normalize(adj + adj.T + I)` of a 0/1
+ * kNN matrix produces (data_loader.py:297-308, utils.py:11-17).  *fail (device int32) is set to 1 if some row has no
+ * such form — arbitrary-valued matrices keep their value stream.  One wave per row.
+ */
+DGMI_API int dgmi_row_multiplicity_f32(const int32_t* indptr, const float* vals, int64_t n_rows, int64_t nnz, float rel_tol,
+                                       float* row_scale, int32_t* mult, int32_t* fail, dgmi_stream_t stream);
 
 /* -------------------------------------------------------------------------
  * (D3 / f1) The per-iteration graph rebuild of the reference (train.py:267 -> augmentation.py:48-65: a new

@@ -136,6 +136,7 @@ void oracle_spmm_csr_abs_f64(const int32_t* indptr, const int32_t* indices,
                              const float* vals, const float* X, int64_t ldx,
                              const float* src_scale, const float* dst_scale,
                              double* Y, int64_t ldy, int64_t n_dst, int64_t F) {
+#pragma omp parallel for schedule(static) /* rows are independent; a bound, so any thread count gives the same values */
   for (int64_t v = 0; v < n_dst; ++v) {
     double* y = Y + v * ldy;
     for (int64_t f = 0; f < F; ++f) y[f] = 0.0;

@@ -23,7 +23,7 @@ def test_header_declares_the_expected_entry_points():
                            "dgmi_probe_row_gather_f32",
                            "dgmi_random_subset_mask_f32", "dgmi_random_subset_select", "dgmi_random_subset_select_batch",
                            "dgmi_random_subset_select_batch_dseed",
-                           "dgmi_random_subset_workspace_bytes", "dgmi_rank_add_f32", "dgmi_scale_rows_f32",
+                           "dgmi_random_subset_workspace_bytes", "dgmi_rank_add_f32", "dgmi_row_multiplicity_f32", "dgmi_scale_rows_f32",
                            "dgmi_set_tuning", "dgmi_spmm_csr_f32", "dgmi_spmm_csr_planned_f32", "dgmi_spmm_default_chunk",
                            "dgmi_spmm_partials_bytes", "dgmi_spmm_plan_build", "dgmi_spmm_plan_bytes",
                            "dgmi_spmm_sliced_f32", "dgmi_spmm_sliced_planes_bytes", "dgmi_status_string", "dgmi_weighted_colsum_f32"]
@@ -98,8 +98,10 @@ def test_argument_validation_returns_codes_without_a_gpu():
     assert L.dgmi_gather_f32(None, None, -3, None, None) == -1
     assert L.dgmi_gather_f32(None, None, 0, None, None) == 0
     # sliced product: column_passes is 0 (by footprint) or 1 (one full-width pass)
-    assert L.dgmi_spmm_sliced_f32(16, 16, None, *K0, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 2, 48, 1 << 20, *E0, None) == -1
-    assert L.dgmi_spmm_sliced_f32(16, 16, None, *K0, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 1, 48, 0, *E0, None) == -3  # planes too small
+    assert L.dgmi_spmm_sliced_f32(16, 16, None, *K0, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 2, 0, 48, 1 << 20, *E0, None) == -1
+    assert L.dgmi_spmm_sliced_f32(16, 16, None, *K0, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 1, 0, 48, 0, *E0, None) == -3  # planes too small
+    assert L.dgmi_spmm_sliced_f32(16, 16, 16, *K0, 16, 4, None, None, 32, 4, 2, 2, 4, 8, 1, 1, 48, 1 << 20, *E0, None) == -1  # vals AND multiplicities
+    assert L.dgmi_row_multiplicity_f32(16, 16, 4, 10, 2.4e-7, 16, 16, None, None) == -1  # no flag word
     # (f4) cosine kNN: shapes the kernels take, workspace sizing, argument checks — host arithmetic only
     assert L.dgmi_knn_cosine_supported(763, 768, 4) == 1 and L.dgmi_knn_cosine_supported(100_000, 768, 16) == 1
     assert L.dgmi_knn_cosine_supported(763, 770, 4) == 0    # D % 8

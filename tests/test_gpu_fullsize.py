@@ -1,6 +1,7 @@
 """BASELINE-size checks on the GPU (config 4: 100k x 50k nodes, 10 M edges, kNN-64 graphs,
-F = 128) through size-independent properties, plus oracle spot checks on sampled rows
-(the CPU oracle on the full 10 M-edge graph would take ~10 s per product on one core)."""
+F = 128): size-independent properties, oracle spot checks on sampled rows, and (r4) EVERY row of every
+product of the bench step against the f64 oracle (the OpenMP oracle does a 10 M-edge product in ~0.1-0.5 s on
+the box's 16 cores: `test_every_row_of_every_config4_product`)."""
 import numpy as np
 import pytest
 import torch
@@ -243,3 +244,71 @@ def test_addresses_beyond_4_gib(oracle, dev):
     assert torch.equal(out[tail], torch.cat([A[s[tail].long()], B[d[tail].long()]], 1))
     ga = ops.gather_add_raw(s, d, A, B)
     assert torch.equal(ga[tail], A[s[tail].long()] + B[d[tail].long()])
+
+
+def _every_row(oracle, g_csr, vals_csr, X, ss, ds, y, what, threads):
+    """All rows, elementwise forward-error bound 1e-5 * sum |terms| against the f64 oracle (tests/test_gpu_configs.py's
+    bar), plus 1e-5 of the output's magnitude."""
+    indptr, indices = g_csr
+    tn = lambda a: None if a is None else a.cpu().numpy()
+    args = (tn(indptr), tn(indices), tn(vals_csr), tn(X), tn(ss), tn(ds))
+    ref = oracle.spmm_csr(*args, acc="f64", threads=threads, validate=False)
+    bound = oracle.spmm_csr(*args, acc="abs", validate=False)
+    err = np.abs(y.cpu().numpy().astype(np.float64) - ref)
+    worst = float((err / (1e-5 * bound + 1e-30)).max())
+    assert worst <= 1.0, "%s: worst element at %.2f of its bound" % (what, worst)
+    assert float(err.max()) <= 1e-5 * float(np.abs(ref).max()), what
+    return worst
+
+
+def test_every_row_of_every_config4_product(oracle, cfg4, dev):
+    """the four GCMC products of bench.py's step (copy_u -> sum with cj / ci fused, forward and
+    transpose, both directions), the kNN-64 product and its transpose (value = row scale x multiplicity form), and
+    one edge-dropped product of each kind — EVERY destination row at 10 M / 12.9 M edges against the f64 oracle
+    (layers.py:224-234, :312)."""
+    from dream_gnn_amd import ops, synth
+
+    drug, dis, g = cfg4
+    threads = oracle.max_threads()
+    gen = torch.Generator(device=dev).manual_seed(3)
+    x_drug = torch.randn(ND, F, generator=gen, device=dev)
+    x_dis = torch.randn(NS, F, generator=gen, device=dev)
+    cj, ci = synth.degree_norm(drug, ND), synth.degree_norm(dis, NS)
+    gr = ops.CSRGraph(drug, dis, ND, NS)  # disease -> drug
+    worst = {}
+    for name, gg, X, ss, ds in (("drug->disease", g, x_drug, cj, ci), ("disease->drug", gr, x_dis, ci, cj)):
+        worst["fwd " + name] = _every_row(oracle, (gg.indptr, gg.indices), None, X, ss, ds, gg.spmm(X, ss, ds), "fwd " + name, threads)
+        it, ix, _, _ = gg.transposed()
+        W = x_dis if gg is g else x_drug  # any (n_dst, F) matrix
+        worst["bwd " + name] = _every_row(oracle, (it, ix), None, W, ds, ss, gg.spmm_t(W, ss, ds), "bwd " + name, threads)
+    assert FORCED or (g._sliced is not None and g._sliced_t is not None)
+    # edge-dropped (what every training step runs, train.py:267): 10 % of the edges, through the compacted layout,
+    # against the oracle on a CSR of the kept edges only
+    keep_n = max(1, int(E * 0.9))
+    desc = ops.random_subset_select(E, keep_n, 99, dev)
+    view = g.dropped(desc)
+    kept = ops.keep_mask(desc, E).bool()
+    gk = ops.csr_from_coo(dis[kept].contiguous(), drug[kept].contiguous(), NS, ND)
+    worst["dropped fwd drug->disease"] = _every_row(oracle, gk[:2], None, x_drug, cj, ci, view.spmm(x_drug, cj, ci),
+                                                    "dropped fwd drug->disease", threads)
+    gkt = ops.csr_from_coo(drug[kept].contiguous(), dis[kept].contiguous(), ND, NS)
+    worst["dropped bwd drug->disease"] = _every_row(oracle, gkt[:2], None, x_dis, ci, cj, view.spmm_t(x_dis, cj, ci),
+                                                    "dropped bwd drug->disease", threads)
+    assert FORCED or not ops.COMPACT_DROPPED or ("sliced" in view._c and "sliced_t" in view._c)
+    del view, gk, gkt, gr
+    # FGCN: th.spmm(adj, support) on the kNN-64 adjacency, forward and transpose, un-dropped and dropped
+    n = ND
+    r, c, v = synth.knn_sim_graph(n, 64, seed=21, device=dev)
+    ga = ops.CSRGraph(r, c, n, n, vals=v)
+    y = ga.spmm(x_drug)
+    assert FORCED or not ops.MULT_FORM or ga._mult_form() is not None  # the reference's format: no value stream
+    worst["fgcn fwd"] = _every_row(oracle, (ga.indptr, ga.indices), ga.vals, x_drug, None, None, y, "fgcn fwd", threads)
+    it, ix, vt, _ = ga.transposed()
+    worst["fgcn bwd"] = _every_row(oracle, (it, ix), vt, x_drug, None, None, ga.spmm_t(x_drug), "fgcn bwd", threads)
+    nnz = ga.nnz
+    desc = ops.random_subset_select(nnz, int(nnz * 0.9), 5, dev)
+    kept = ops.keep_mask(desc, nnz).bool()
+    ik, xk, ek = ops.csr_from_coo(r[kept].contiguous(), c[kept].contiguous(), n, n)
+    vk = ops.gather_f32(v[kept].contiguous(), ek)
+    worst["fgcn dropped fwd"] = _every_row(oracle, (ik, xk), vk, x_drug, None, None, ga.dropped(desc).spmm(x_drug), "fgcn dropped fwd", threads)
+    print("worst element / bound per product:", {k: round(w, 3) for k, w in worst.items()})

@@ -923,3 +923,119 @@ def test_edge_dropped_view_of_a_sliced_graph_compacted_or_on_the_fly(oracle, dev
     ip2, ix2, e2 = oracle.csr_from_coo(dst[mask2], src[mask2], n_dst)
     ref2 = oracle.spmm_csr(ip2, ix2, None if vals is None else vals[mask2][e2], X, ss, ds, acc="f64")
     assert np.abs(view2.spmm(t(X), t(ss), t(ds)).cpu().numpy() - ref2).max() <= RTOL * max(np.abs(ref2).max(), 1e-30)
+
+
+def _reference_adjacency(rng, n, k, dup_self=False):
+    """`normalize(adj + adj.T + I)` of a 0/1 kNN matrix as the reference builds it (data_loader.py:297-308,
+    utils.py:11-17: float64 row sums, values cast to fp32), neighbours random; COO (row, col, val), row-major."""
+    import scipy.sparse as sp
+
+    rows = np.repeat(np.arange(n), k)
+    cols = rng.integers(0, n, n * k)
+    if dup_self:
+        cols[::k] = rows[::k]  # self in the top-k, as a cosine kNN always has it: diagonal multiplicity 3
+    a = sp.coo_matrix((np.ones(n * k), (rows, cols)), shape=(n, n)).tocsr()
+    a.data[:] = 1.0  # a 0/1 matrix (duplicate picks collapse)
+    a = a + a.T + sp.eye(n)
+    r_inv = np.power(np.asarray(a.sum(1)).ravel(), -1.0)
+    a = sp.diags(r_inv).dot(a).tocoo()
+    return a.row.astype(np.int32), a.col.astype(np.int32), a.data.astype(np.float32)
+
+
+def test_row_multiplicity_finds_the_reference_adjacency_form_and_only_that(dev):
+    """`dgmi_row_multiplicity_f32`: an adjacency built the reference's way is row scale x m (m in 1..3 here) to 2 ulp in
+    every row; arbitrary values, a zero / negative value or a multiplicity of 9 in ONE row raise the flag."""
+    from dream_gnn_amd import _lib, ops
+
+    rng = np.random.default_rng(3)
+    n = 3000
+    r, c, v = _reference_adjacency(rng, n, 6, dup_self=True)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    g = ops.CSRGraph(t(r), t(c), n, n, vals=t(v))
+    scale, code, fail = _lib.torch_ops.row_multiplicity(g.indptr, g.vals, ops.MULT_REL_TOL)
+    assert int(fail.item()) == 0
+    code, scale = code.cpu().numpy(), scale.cpu().numpy()
+    assert code.min() == 0 and code.max() == 2 and (code == 2).sum() >= n  # the diagonal: A + A^T + I = 3
+    rows = np.repeat(np.arange(n), np.diff(g.indptr.cpu().numpy()))
+    vals_csr = g.vals.cpu().numpy()
+    assert np.all(np.abs((code + 1) * scale[rows] - vals_csr) <= 2.4e-7 * vals_csr)
+    mf = g._mult_form()
+    assert mf is not None and torch.equal(mf[1][g.eid.long()].cpu(), torch.from_numpy(code))
+    for name, v2 in (("random", rng.uniform(0.1, 1.0, v.size).astype(np.float32)),
+                     ("one zero", np.where(np.arange(v.size) == 17, 0.0, v).astype(np.float32)),
+                     ("one negative", np.where(np.arange(v.size) == 17, -v, v).astype(np.float32)),
+                     ("one off by 1e-5", np.where(np.arange(v.size) == 17, v * (1 + 1e-5), v).astype(np.float32))):
+        g2 = g.with_values(t(v2))
+        assert int(_lib.torch_ops.row_multiplicity(g2.indptr, g2.vals, ops.MULT_REL_TOL)[2].item()) == 1, name
+        assert g2._mult_form() is None, name
+    # multiplicities up to 8 are carried, 9 is not
+    r3 = np.concatenate([np.zeros(9, np.int32), np.array([1, 1], np.int32)])
+    c3 = np.arange(11, dtype=np.int32)
+    for top, want in ((8, 0), (9, 1)):
+        v3 = np.concatenate([np.arange(1, 10, dtype=np.float32).clip(max=top) * np.float32(0.01), [0.5, 0.5]]).astype(np.float32)
+        v3[8] = top * np.float32(0.01)
+        g3 = ops.CSRGraph(t(r3), t(c3), 3, 11, vals=t(v3))  # row 2 is empty
+        assert int(_lib.torch_ops.row_multiplicity(g3.indptr, g3.vals, ops.MULT_REL_TOL)[2].item()) == want
+
+
+@pytest.mark.parametrize("F", [128, 64, 256])
+@pytest.mark.parametrize("scaled", [False, True])
+def test_weighted_product_without_a_value_stream_equals_the_weighted_product(oracle, dev, monkeypatch, F, scaled):
+    """(r4) An adjacency in the reference's format through the XCD-local kernels with the multiplicity in the id words
+    and the row scale as a diagonal scale: every row of the product and of its transpose within 1e-5 of the f64 oracle
+    ON THE ORIGINAL VALUES (and of on-device `torch.spmm`), un-dropped, edge-dropped after compaction and edge-dropped
+    on the fly; the same graph with DGMI_MULT_FORM off (value stream) agrees to fp32 rounding; an arbitrary-valued
+    graph keeps its value stream."""
+    from dream_gnn_amd import ops
+
+    monkeypatch.setattr(ops, "FORCE_KERNEL", "sliced")
+    rng = np.random.default_rng(F + scaled)
+    n = 2500
+    r, c, v = _reference_adjacency(rng, n, 8, dup_self=True)
+    E = r.size
+    X = rng.standard_normal((n, F)).astype(np.float32)
+    W = rng.standard_normal((n, F)).astype(np.float32)
+    ss = rng.uniform(0.5, 1.5, n).astype(np.float32) if scaled else None
+    ds = rng.uniform(0.5, 1.5, n).astype(np.float32) if scaled else None
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    g = ops.CSRGraph(t(r), t(c), n, n, vals=t(v))
+    assert g._mult_form() is not None
+    keep_n = int(E * 0.9)
+    desc = ops.random_subset_select(E, keep_n, 7, dev)
+    full = np.ones(E, bool)
+    dropped = oracle.random_subset_mask(E, keep_n, 7).astype(bool)
+
+    def refs(mask):
+        ip, ix, e0 = oracle.csr_from_coo(r[mask], c[mask], n)
+        y = oracle.spmm_csr(ip, ix, v[mask][e0], X, ss, ds, acc="f64"), oracle.spmm_csr(ip, ix, v[mask][e0], X, ss, ds, acc="abs")
+        tp, ti, te = oracle.csr_from_coo(c[mask], r[mask], n)
+        dx = oracle.spmm_csr(tp, ti, v[mask][te], W, ds, ss, acc="f64"), oracle.spmm_csr(tp, ti, v[mask][te], W, ds, ss, acc="abs")
+        return y, dx
+
+    for mask, view, compact in ((full, g, True), (dropped, g.dropped(desc), True), (dropped, g.dropped(desc), False)):
+        monkeypatch.setattr(ops, "COMPACT_DROPPED", compact)
+        (y64, yabs), (dx64, dxabs) = refs(mask)
+        y = view.spmm(t(X), t(ss), t(ds)).cpu().numpy()
+        dx = view.spmm_t(t(W), t(ss), t(ds)).cpu().numpy()
+        assert np.all(np.abs(y - y64) <= RTOL * yabs + 1e-30) and np.all(np.abs(dx - dx64) <= RTOL * dxabs + 1e-30)
+        if view is not g and compact:
+            assert view._c["sliced"].id_mult and view._c["sliced"].vals is None
+    assert "sliced" not in g._v and "sliced/ids" in g._v  # the value stream of this layout was never built
+    if not scaled:  # the reference's own call, on the device
+        adj = torch.sparse_coo_tensor(torch.stack([t(r).long(), t(c).long()]), t(v), (n, n))
+        y_t = torch.spmm(adj, t(X))
+        assert float((g.spmm(t(X)) - y_t).abs().max()) <= RTOL * float(y_t.abs().max())
+    # value-stream form of the same graph
+    monkeypatch.setattr(ops, "MULT_FORM", False)
+    gv = ops.CSRGraph(t(r), t(c), n, n, vals=t(v))
+    yv = gv.spmm(t(X), t(ss), t(ds))
+    assert gv._mult_form() is None and "sliced" in gv._v
+    assert float((yv - g.spmm(t(X), t(ss), t(ds))).abs().max()) <= RTOL * float(yv.abs().max())
+    monkeypatch.setattr(ops, "MULT_FORM", True)
+    # arbitrary values: value stream, same answer as the oracle
+    va = rng.standard_normal(E).astype(np.float32)
+    ga = ops.CSRGraph(t(r), t(c), n, n, vals=t(va))
+    ip, ix, e0 = oracle.csr_from_coo(r, c, n)
+    ya = ga.spmm(t(X)).cpu().numpy()
+    assert ga._mult_form() is None and "sliced" in ga._v
+    assert np.all(np.abs(ya - oracle.spmm_csr(ip, ix, va[e0], X, acc="f64")) <= RTOL * oracle.spmm_csr(ip, ix, va[e0], X, acc="abs") + 1e-30)
