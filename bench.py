@@ -485,17 +485,53 @@ def model_steps(torch, dev):
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t0) / n * 1e3
 
+            from dream_gnn_amd import layers as L
+
             torch.manual_seed(0)
             net = M.Net(args).to(dev)
             opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-5)
             eager = wall(lambda: H.train_step(net, opt, batch, y))
-            torch.manual_seed(0)
-            net = M.Net(args).to(dev)
-            opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-5, capturable=True)
-            step = H.CapturedTrainStep(net, opt, batch, y)
-            out[cfg] = {"train_pairs": int(drug.numel()), "nodes": "%dx%d" % (nd, ns), "width": width,
-                        "training_step_eager_ms": round(eager, 3), "training_step_hip_graph_replay_ms": round(wall(step), 3)}
-            del step, net, opt, batch
+            entry = {"train_pairs": int(drug.numel()), "nodes": "%dx%d" % (nd, ns), "width": width,
+                     "training_step_eager_ms": round(eager, 3), "complement_form_default": L.GCMCLayer.complement_form}
+            # the relation-fused aggregate in its two forms (f3: plain CSR / column sum - complement), device time of the
+            # recorded training iteration (augmentation on) and of the recorded eval forward: what decides the default
+            default_form = L.GCMCLayer.complement_form
+            try:
+                for form, flag in (("plain", False), ("complement", True)):
+                    L.GCMCLayer.complement_form = flag
+                    torch.manual_seed(0)
+                    net = M.Net(args).to(dev)
+                    opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-5, capturable=True)
+                    step = H.CapturedTrainStep(net, opt, batch, y)
+                    entry["training_step_hip_graph_replay_ms " + form] = round(wall(step, n=40), 3)
+                    del step
+                    net.eval()
+                    fwd = lambda: net(batch["enc_graph"], batch["dec_graph"], batch["drug_graph"], batch["drug_sim_feat"],
+                                      batch["drug_feat"], batch["disease_graph"], batch["disease_sim_feat"], batch["disease_feat"],
+                                      batch.get("drug_feature_graph"), batch.get("disease_feature_graph"))[0]
+                    with torch.no_grad():
+                        side = torch.cuda.Stream()
+                        side.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(side):
+                            for _ in range(3):
+                                fwd()
+                        torch.cuda.current_stream().wait_stream(side)
+                        torch.cuda.synchronize()
+                        gr = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gr):
+                            fwd()
+                    entry["eval_forward_hip_graph_replay_ms " + form] = round(wall(gr.replay, n=40), 3)
+                    del gr, net, opt
+                    torch.cuda.empty_cache()
+            finally:
+                L.GCMCLayer.complement_form = default_form
+            # the defaults: training -> plain unless forced on; eval -> complement unless forced off (layers.GCMCLayer.complement_form)
+            entry["training_step_hip_graph_replay_ms"] = entry["training_step_hip_graph_replay_ms " +
+                                                               ("complement" if default_form is True else "plain")]
+            entry["eval_forward_hip_graph_replay_ms"] = entry["eval_forward_hip_graph_replay_ms " +
+                                                              ("plain" if default_form is False else "complement")]
+            out[cfg] = entry
+            del batch
             torch.cuda.empty_cache()
         except Exception as exc:  # noqa: BLE001 - context numbers must never cost the bench its line
             out[cfg] = {"error": repr(exc)}
@@ -509,7 +545,7 @@ def model_steps_in_child():
 
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--model-steps-child"], capture_output=True, text=True,
-                           timeout=240, env=dict(os.environ, DGMI_SKIP_BUILD="1"))
+                           timeout=480, env=dict(os.environ, DGMI_SKIP_BUILD="1"))
         for line in reversed(r.stdout.strip().splitlines()):
             if line.startswith("{"):
                 return json.loads(line)

@@ -575,6 +575,17 @@ def _bipartite_blocks(present: torch.Tensor, max_blocks: int = 8):
     return blk_dst.to(torch.int64), blk_src.to(torch.int64), int(roots.numel())
 
 
+def _randperm(n: int, device, generator: Optional[torch.Generator]) -> torch.Tensor:
+    """``torch.randperm(n, device=device)`` as the reference draws it (augmentation.py:51,117).  With a CPU generator
+    and a GPU graph the permutation is drawn on the HOST and copied over — the generator decides where the draw
+    happens, so two runs fed the same CPU generator state see the same subsets whatever device their graphs live on
+    (the training-curve parity check of SURVEY 8(d)); no generator / a device generator: the device RNG, as upstream."""
+    device = torch.device(device)
+    if generator is not None and generator.device.type == "cpu" and device.type != "cpu":
+        return torch.randperm(n, generator=generator).to(device)
+    return torch.randperm(n, device=device, generator=generator)
+
+
 def _draw_seed(generator: Optional[torch.Generator]) -> Optional[int]:
     """A 62-bit seed from a CPU generator (or torch's default CPU RNG) without touching the GPU;
     None when the caller handed in a device generator (the randperm path is used then)."""
@@ -609,7 +620,7 @@ def _select_kept(E: int, keep: int, device, generator, selection: Optional[str])
         seed = _draw_seed(generator)
         if seed is not None:
             return None, ops.random_subset_select(E, keep, seed, device)
-    return torch.randperm(E, device=device, generator=generator)[:keep], None
+    return _randperm(E, device, generator)[:keep], None
 
 
 def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
@@ -637,7 +648,7 @@ def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
             src, dst = rel.src, rel.dst
             if E:
                 keep = max(1, int(E * (1 - dropout_rate)))
-                perm = torch.randperm(E, device=rel.device, generator=generator)[:keep]
+                perm = _randperm(E, rel.device, generator)[:keep]
                 src, dst = src[perm], dst[perm]
             child = RelationGraph(can, src, dst, rel.n_src, rel.n_dst, out._ndata[st], out._ndata[dt])
             child.trusted = True  # a subset of an existing graph's edges: no range re-check, no host sync
@@ -654,7 +665,7 @@ def random_edge_dropout(graph: HeteroGraph, dropout_rate: float = 0.1,
             out._rels[can] = None  # keeps the canonical position
             pending.append((can, rel, keep, seed))
         else:
-            keep_idx = torch.randperm(E, device=rel.device, generator=generator)[:keep]
+            keep_idx = _randperm(E, rel.device, generator)[:keep]
             out._rels[can] = DroppedRelation(rel, keep, out._ndata[st], out._ndata[dt], keep_idx=keep_idx)
     if pending:
         dev0 = pending[0][1].device
@@ -694,7 +705,7 @@ def random_edge_dropout_sparse(adj, dropout_rate: float = 0.1, generator: Option
             idx = torch.nonzero(alive, as_tuple=False).reshape(-1)
             E = int(idx.numel())
             keep = max(1, int(E * (1 - dropout_rate))) if E else 0
-            perm = torch.randperm(E, device=base.device, generator=generator)[:keep]
+            perm = _randperm(E, base.device, generator)[:keep]
             mask = torch.zeros(base.nnz, dtype=torch.float32, device=base.device).index_fill_(0, idx[perm], 1.0)
             return base.undropped().masked(mask)
         E = base.nnz
@@ -706,7 +717,7 @@ def random_edge_dropout_sparse(adj, dropout_rate: float = 0.1, generator: Option
     idx, val = adj._indices(), adj._values()
     E = val.shape[0]
     keep = max(1, int(E * (1 - dropout_rate)))
-    perm = torch.randperm(E, device=adj.device, generator=generator)[:keep]
+    perm = _randperm(E, adj.device, generator)[:keep]
     out = torch.sparse_coo_tensor(idx[:, perm], val[perm], adj.shape, device=adj.device)
     out._dgmi_trusted = True  # a subset of a valid adjacency: adjacency_csr skips the id re-check (no host sync)
     # layers.adjacency_csr applies the dropout as a keep mask over the parent's CSR instead of
@@ -732,8 +743,9 @@ def random_edge_dropout_sparse_views(adjs, dropout_rate: float = 0.1, generator:
     if not bases:
         return []
     on_device = selection == "select_device" and bases[0].device.type == "cuda"
-    if not on_device and (bases[0].device.type != "cuda" or (generator is not None and generator.device.type != "cpu")):
-        return [random_edge_dropout_sparse(a, dropout_rate, generator, as_view=True) for a in adjs]
+    if selection == "randperm" or (not on_device and (bases[0].device.type != "cuda" or
+                                                      (generator is not None and generator.device.type != "cpu"))):
+        return [random_edge_dropout_sparse(a, dropout_rate, generator, as_view=True, selection=selection) for a in adjs]
     if any(b.survivors() is not None for b in bases):  # a dropout of dropped views: exact counts of the survivors
         return [random_edge_dropout_sparse(b, dropout_rate, generator, as_view=True) for b in bases]
     keeps = [max(1, int(b.nnz * (1 - dropout_rate))) for b in bases]

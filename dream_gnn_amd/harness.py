@@ -43,7 +43,10 @@ def augment(batch: Dict, edge_dropout_rate: float = 0.1, feature_noise_scale: fl
                      ("drug_sim_feat", sim_noise_scale), ("disease_sim_feat", sim_noise_scale)):
         if batch.get(k) is not None:
             x = batch[k]
-            noise = torch.randn(x.shape, dtype=x.dtype, device=x.device, generator=generator)
+            if generator is not None and generator.device.type == "cpu" and x.device.type != "cpu":
+                noise = torch.randn(x.shape, dtype=x.dtype, generator=generator).to(x.device)  # host draw, as graph._randperm
+            else:
+                noise = torch.randn(x.shape, dtype=x.dtype, device=x.device, generator=generator)
             out[k] = x + noise * scale
     return out
 
@@ -61,10 +64,12 @@ def forward_loss(net, batch: Dict, labels: torch.Tensor, beta: float):
 
 
 def train_step(net, optimizer, batch: Dict, labels: torch.Tensor, beta: float = 0.1, grad_clip: float = 1.0,
-               do_augment: bool = True, generator: Optional[torch.Generator] = None) -> torch.Tensor:
-    """One iteration of train.py:249-300.  Returns the (detached) total loss."""
+               do_augment: bool = True, generator: Optional[torch.Generator] = None,
+               selection: Optional[str] = None) -> torch.Tensor:
+    """One iteration of train.py:249-300.  Returns the (detached) total loss.  ``generator`` / ``selection``: where the
+    augmentation's draws come from (``augment``)."""
     net.train()
-    step_batch = augment(batch, generator=generator) if do_augment else batch
+    step_batch = augment(batch, generator=generator, selection=selection) if do_augment else batch
     loss, _ = forward_loss(net, step_batch, labels, beta)
     optimizer.zero_grad()
     loss.backward()
@@ -90,6 +95,10 @@ class CapturedTrainStep:
 
     def __init__(self, net, optimizer, batch: Dict, labels: torch.Tensor, beta: float = 0.1, grad_clip: float = 1.0,
                  do_augment: bool = True, warmup: int = 3):
+        """NOTE: constructing the object TRAINS: ``warmup`` (>= 1, default 3) real iterations run eagerly on a side stream
+        before the recording (layouts, plans and autotuned library kernels must exist before a capture), and the
+        recording itself executes nothing.  Parameters, Adam moments / step count and the RNG streams advance by
+        ``warmup`` steps: N replays after construction leave the model where ``warmup + N`` eager steps would."""
         if not labels.is_cuda:
             raise RuntimeError("CapturedTrainStep records a HIP graph: the model and its inputs must be on the GPU")
         if not all(g.get("capturable", False) for g in optimizer.param_groups):

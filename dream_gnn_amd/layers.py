@@ -313,8 +313,16 @@ class GCMCLayer(nn.Module):
 
     #: f3 complement form — a relation that covers most cells of its block (the reference's label-0 slice: 89 %,
     #: data_loader.py:146-150,170) is evaluated as `colsum - complement` over ~8x fewer edges (graph.py
-    #: HeteroGraph.fused_relations_complement).  Set False for the plain fused CSR.
-    complement_form = True
+    #: HeteroGraph.fused_relations_complement).  True / False force it on / off; "eval" (default) uses it in eval mode only.
+    #: Decided by measurement (round 4, bench.py `model_steps`, recorded steps = device time): the recorded EVAL forward
+    #: is 4-5 % faster in complement form (lrssl shape 1.023 -> 0.982 ms, C+G 1.069 -> 1.018: the column-sum coefficients
+    #: are constants of the graph there), the recorded TRAINING iteration is not (5.194 -> 5.219 ms, 5.029 -> 5.066: the
+    #: product's gain is spent on the column sums, their gradient and the per-step coefficients under dropout).  Both forms
+    #: meet the same gradient bounds against an f64 evaluation of the whole model (tests/test_gpu_configs.py).
+    complement_form = "eval"
+
+    def _use_complement(self) -> bool:
+        return (not self.training) if self.complement_form == "eval" else bool(self.complement_form)
 
     #: f3 epilogue — `dropout(agg_act(sum over relations))` (layers.py:134-138) inside the kernel that
     #: writes the aggregated messages.  Needs an activation the kernels know (LeakyReLU / ReLU / none).
@@ -412,7 +420,7 @@ class GCMCLayer(nn.Module):
             w_cat = torch.cat([F.pad(weights[c], (0, pad)) if pad else weights[c] for c in cans], dim=1)
             scale = torch.stack([drops[c] for c in cans], dim=1).reshape(-1)
             ci = graph[cans[0]].dstdata["ci"]
-            comp = graph.fused_relations_complement(nt) if self.complement_form and hasattr(graph, "fused_relations_complement") else None
+            comp = graph.fused_relations_complement(nt) if self._use_complement() and hasattr(graph, "fused_relations_complement") else None
             if comp is not None:
                 # near-complete relation i0: A_0 H = 1 colsum(H)^T - C H.  The column sum of
                 # scale_i0 * feat_i0 becomes the feature row of ONE virtual source per block of the relation (one block

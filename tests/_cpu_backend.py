@@ -32,8 +32,28 @@ def gather_f32(values, perm):
 
 def spmm_csr_raw(indptr, indices, vals, X, src_scale=None, dst_scale=None, out=None, plan=None):
     n = lambda t: None if t is None else t.detach().cpu().numpy()
-    y = O.spmm_csr(n(indptr), n(indices), n(vals), np.ascontiguousarray(n(X)), n(src_scale), n(dst_scale))
+    # rows in parallel, each row summed sequentially in fp32: the same values for any thread count
+    y = O.spmm_csr(n(indptr), n(indices), n(vals), np.ascontiguousarray(n(X)), n(src_scale), n(dst_scale), threads=O.max_threads())
     y = torch.from_numpy(y)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def spmm_csr_raw_f64(indptr, indices, vals, X, src_scale=None, dst_scale=None, out=None, plan=None):
+    """The same product evaluated in float64 end to end (torch sparse CSR @ dense, double): the backend of an f64
+    evaluation of the whole model (`patched(f64=True)`, the model and its inputs cast to double), against which two fp32
+    evaluations can be told apart from each other's rounding."""
+    n_dst = indptr.shape[0] - 1
+    v = torch.ones(indices.shape[0], dtype=torch.float64) if vals is None else vals.detach().double()
+    Xd = X.detach().double()
+    if src_scale is not None:
+        Xd = Xd * src_scale.detach().double().reshape(-1, 1)
+    y = torch.sparse_csr_tensor(indptr.long(), indices.long(), v, (n_dst, Xd.shape[0])) @ Xd
+    if dst_scale is not None:
+        y = y * dst_scale.detach().double().reshape(-1, 1)
+    y = y.to(X.dtype)
     if out is not None:
         out.copy_(y)
         return out
@@ -82,7 +102,7 @@ def _launch_spmm(dev, indptr, indices, vals, X, src_scale, dst_scale, out, plan,
     if keep is not None:  # edge dropout on the fly: position p takes part iff keep(eid[p])
         m = keep_mask(keep, int(eid.max()) + 1 if eid.numel() else 0)[eid.long()]
         vals = m if vals is None else vals * m
-    y = spmm_csr_raw(indptr, indices, vals, X, src_scale, dst_scale, out=out)
+    y = (spmm_csr_raw_f64 if _F64[0] else spmm_csr_raw)(indptr, indices, vals, X, src_scale, dst_scale, out=out)
     if epi is not None:  # the kernels' output epilogue: activation, then the dropout keep mask
         act, slope, mask, mscale = epi
         if act == 1:
@@ -109,14 +129,20 @@ def epilogue_backward(dY, Y, mask, act, slope, mask_scale):
     return g if mask is None else g * mask * mask_scale
 
 
+_F64 = [False]
+
+
 @contextlib.contextmanager
-def patched():
+def patched(f64=False):
+    """``f64=True``: the SpMM stand-in evaluates in float64 (for a model cast to double)."""
     from dream_gnn_amd import ops
+
+    _F64[0] = bool(f64)
 
     names = ("csr_from_coo", "gather_f32", "spmm_csr_raw", "_launch_spmm", "_require_device", "build_plan", "FORCE_KERNEL",
              "gather_concat_raw", "gather_add_raw", "random_subset_mask", "random_subset_select", "random_subset_select_batch", "keep_mask", "epilogue_backward", "colsum_rows_", "colsum_rows_backward_")
     saved = {k: getattr(ops, k) for k in names}
-    ops.csr_from_coo, ops.gather_f32, ops.spmm_csr_raw = csr_from_coo, gather_f32, spmm_csr_raw
+    ops.csr_from_coo, ops.gather_f32, ops.spmm_csr_raw = csr_from_coo, gather_f32, (spmm_csr_raw_f64 if f64 else spmm_csr_raw)
     ops._launch_spmm = _launch_spmm
     ops.gather_concat_raw = gather_concat_raw
     ops.gather_add_raw = gather_add_raw
@@ -133,5 +159,6 @@ def patched():
     try:
         yield
     finally:
+        _F64[0] = False
         for k, v in saved.items():
             setattr(ops, k, v)

@@ -160,14 +160,71 @@ def test_lrssl_knn4_adjacencies_every_row(oracle, lrssl, dev):
             assert float((y - ref).abs().max()) <= RTOL * float(ref.abs().max())
 
 
-def _module_parity(dev, blocks, out_units, seed, complement=False):
-    """Net forward + loss + backward on the HIP path vs the same modules on the CPU with the
-    oracle as op backend, identical parameters and inputs, no stochastic layers."""
+def _model_grads(device, blocks, out_units, seed, complement, state=None, f64=False):
+    """(loss, logits, parameter gradients, state_dict) of one forward + backward of the full Net, no stochastic
+    layers; ``f64``: everything cast to double (CPU, float64 SpMM backend)."""
     from dream_gnn_amd import harness as H, layers as L, model as M, synth
 
-    res = {}
+    old = L.GCMCLayer.complement_form
     L.GCMCLayer.complement_form = complement
+    try:
+        batch, labels = synth.dataset_shaped_batch(blocks, emb=768, k=4, seed=seed, device=device)
+        args = synth.net_args(out_units=out_units, n_drug=batch["n_drug"], n_dis=batch["n_dis"], dropout=0.0, attention_dropout=0.0)
+        torch.manual_seed(7)
+        net = M.Net(args)
+        if state is not None:
+            net.load_state_dict(state)
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        if f64:
+            net = net.double()
+            batch = {k: (v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in batch.items()}
+            labels = labels.double()
+        net = net.to(device).train()
+        loss, pred = H.forward_loss(net, batch, labels, beta=0.1)
+        loss.backward()
+        return (float(loss.detach()), pred.detach().cpu().double(),
+                {k: p.grad.detach().cpu().double() for k, p in net.named_parameters() if p.grad is not None}, state)
+    finally:
+        L.GCMCLayer.complement_form = old
+
+
+@pytest.mark.parametrize("blocks_name,out_units", [("lrssl", 128), ("C+G", 256)])
+def test_full_model_gradients_of_both_forms_against_an_f64_evaluation(oracle, dev, blocks_name, out_units):
+    """VERDICT r3 item 3(i): the plain fused form and the COMPLEMENT form (f3) are two fp32 evaluations of the same model;
+    compared with each other (HIP vs CPU-oracle path) the complement form looked 60x worse on the parameters whose
+    gradient is a near-total cancellation over all nodes (1.7e-2 vs 2.7e-4 of the tensor's max on TGCN.0.basis).
+    Against an evaluation of the whole model in float64 (CPU, torch double, float64 SpMM) both forms are held to the SAME
+    bounds: 1e-4 of the tensor's maximum for every GCMC-channel weight (TGCN.*.att / basis / ufc.weight — where the forms
+    differ), 1e-3 for everything else (bias gradients are cancelling sums over every node / pair: 6e-4 on
+    TGCN.0.ufc.bias at the merged shape in the PLAIN form; FGCN.gc1 sits behind a relu whose sign flips under fp32
+    rounding: 7e-4 already between MKL fp32 and float64 on the CPU) — and the complement form may not be worse than the
+    plain one by more than rounding noise (3x, or 1e-4)."""
+    from dream_gnn_amd import synth
+
+    blocks = [synth.DATASET_SHAPES["lrssl"]] if blocks_name == "lrssl" else [synth.DATASET_SHAPES["Cdataset"], synth.DATASET_SHAPES["Gdataset"]]
+    seed = 0 if blocks_name == "lrssl" else 1
+    with _cpu_backend.patched(f64=True):
+        l64, p64, g64, state = _model_grads(torch.device("cpu"), blocks, out_units, seed, complement=False, f64=True)
+    worst = {}
+    for complement in (False, True):
+        l, p, g, _ = _model_grads(dev, blocks, out_units, seed, complement=complement, state=state)
+        assert abs(l - l64) <= 1e-5 * max(1.0, abs(l64))
+        assert float((p - p64).abs().max()) <= 1e-4 * float(p64.abs().max())
+        assert set(g) == set(g64)
+        worst[complement] = {k: float((g[k] - g64[k]).abs().max()) / max(float(g64[k].abs().max()), 1e-30) for k in g64}
+    top = lambda d: sorted(((round(e, 7), k) for k, e in d.items() if k.startswith("TGCN.")), reverse=True)[:4]
+    print("%s: worst TGCN gradient errors vs f64 — plain %s; complement %s" % (blocks_name, top(worst[False]), top(worst[True])))
+    for complement in (False, True):
+        for k, e in worst[complement].items():
+            tight = k.startswith("TGCN.") and not k.endswith(".bias")
+            assert e <= (1e-4 if tight else 1e-3), (("complement" if complement else "plain"), k, e)
+    for k, e in worst[True].items():
+        assert e <= max(3.0 * worst[False][k], 1e-4), ("complement form worse than the plain one", k, e, worst[False][k])
+
+
+def _module_parity_runs(dev, blocks, out_units, seed, res, H, M, synth):
     for where in ("gpu", "cpu"):
+
         device = dev if where == "gpu" else torch.device("cpu")
         ctx = _cpu_backend.patched() if where == "cpu" else None
         if ctx is not None:
@@ -193,7 +250,20 @@ def _module_parity(dev, blocks, out_units, seed, complement=False):
         finally:
             if ctx is not None:
                 ctx.__exit__(None, None, None)
-    L.GCMCLayer.complement_form = True
+
+
+def _module_parity(dev, blocks, out_units, seed, complement=False):
+    """Net forward + loss + backward on the HIP path vs the same modules on the CPU with the
+    oracle as op backend, identical parameters and inputs, no stochastic layers."""
+    from dream_gnn_amd import harness as H, layers as L, model as M, synth
+
+    res = {}
+    default_form = L.GCMCLayer.complement_form
+    L.GCMCLayer.complement_form = complement
+    try:
+        _module_parity_runs(dev, blocks, out_units, seed, res, H, M, synth)
+    finally:
+        L.GCMCLayer.complement_form = default_form  # whatever the outcome (ADVICE r3)
     (gl, gp, gg), (cl, cp, cg) = res["gpu"], res["cpu"]
     assert abs(gl - cl) <= 1e-5 * max(1.0, abs(cl)), (gl, cl)
     assert float((gp - cp).abs().max()) <= 1e-4 * float(cp.abs().max()), "logits"
@@ -207,7 +277,9 @@ def _module_parity(dev, blocks, out_units, seed, complement=False):
     # the nodes the way independent per-row roundings do, and the parameters whose gradient is a near-total
     # cancellation over all nodes (TGCN.0.basis: max 2e-3 here) see it: measured 1.7e-2 of the tensor's max, against
     # 2.7e-4 in the plain form.  Both are fp32 evaluations of equal accuracy — against an f64 evaluation of one layer the
-    # two forms' gradients err by 8e-7 and 1.1e-6 of the max (tools/complement_check.py) — so the bound is looser here,
+    # two forms' gradients err by 8e-7 and 1.1e-6 of the max (tools/complement_check.py), and against an f64 evaluation of
+    # the WHOLE model both meet the same bounds (test_full_model_gradients_of_both_forms_against_an_f64_evaluation: 4.2e-5 /
+    # 4.4e-5 on the worst TGCN tensor at lrssl shape) — so the bound between the two fp32 evaluations is looser here,
     # the forward (loss, logits) is held to the same 1e-5 / 1e-4 as the plain form.
     tol = 5e-2 if complement else 1e-3
     for k in cg:

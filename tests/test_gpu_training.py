@@ -227,3 +227,57 @@ def test_decoder_stages_fused_relu_and_one_pass_backward(dev):
     assert float((y_g - y_w).abs().max()) <= 1e-5 * float(y_w.abs().max())
     for g, wv in zip(got[1:], want[1:]):
         assert float((g - wv).abs().max()) <= 1e-4 * float(wv.abs().max())
+
+
+def _host_dropout(gen):
+    """`F.dropout` with the keep mask drawn on the HOST from `gen` (inverted dropout, as torch): the same masks reach
+    the HIP path and the CPU-oracle path, in the order the modules ask for them."""
+    def dropout(input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return input
+        keep = (torch.rand(input.shape, generator=gen) >= p).to(input.dtype).to(input.device)
+        return input * keep / (1.0 - p)
+    return dropout
+
+
+def _train_lrssl_shaped(device, steps, state, seed_draws):
+    from dream_gnn_amd import harness as H, model as M, synth
+
+    batch, labels = synth.dataset_shaped_batch([synth.DATASET_SHAPES["lrssl"]], emb=768, k=4, seed=0, device=device)
+    args = synth.net_args(out_units=128, n_drug=batch["n_drug"], n_dis=batch["n_dis"], dropout=0.1, attention_dropout=0.1)
+    torch.manual_seed(11)
+    net = M.Net(args)
+    if state is not None:
+        net.load_state_dict(state)
+    init = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(device)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-3, weight_decay=1e-5)
+    aug_gen = torch.Generator().manual_seed(seed_draws)          # edge subsets + feature noise (host draws)
+    drop_gen = torch.Generator().manual_seed(seed_draws + 1)     # every dropout mask (host draws)
+    real = torch.nn.functional.dropout
+    torch.nn.functional.dropout = _host_dropout(drop_gen)
+    try:
+        losses = [float(H.train_step(net, opt, batch, labels, beta=0.1, do_augment=True, generator=aug_gen, selection="randperm"))
+                  for _ in range(steps)]
+    finally:
+        torch.nn.functional.dropout = real
+    return losses, H.evaluate(net, batch, labels), init
+
+
+def test_training_curve_with_dropout_and_augmentation_from_host_draws(oracle, dev):
+    """SURVEY 8(d)(b) as written: lrssl shape (763 x 681, 467 643 train pairs, 3 GCMC layers
+    341 -> 128 -> 128 + FGCN + attention + decoder), 10 Adam steps of train.py:249-300 WITH dropout 0.1 and the
+    reference's per-step augmentation (edge dropout 0.1 on the encoder graph and the four adjacencies as the literal
+    `randperm(E)[:keep]`, feature noise 0.05 — augmentation.py:13-124,208-241), every random draw made on the host from
+    one generator state and fed to both the HIP path and the CPU-oracle path: loss curves within 1e-4, final
+    AUROC / AUPR (evaluation.py:60-65) within 1e-3."""
+    steps = 10
+    gpu_losses, (ga, gp), init = _train_lrssl_shaped(dev, steps, None, 2026)
+    with _cpu_backend.patched():
+        cpu_losses, (ca, cp), _ = _train_lrssl_shaped(torch.device("cpu"), steps, init, 2026)
+    gap = max(abs(a - b) for a, b in zip(gpu_losses, cpu_losses))
+    print("loss curves: hip %s | cpu-oracle %s | max gap %.2e; AUROC %.5f / %.5f, AUPR %.5f / %.5f"
+          % ([round(v, 5) for v in gpu_losses], [round(v, 5) for v in cpu_losses], gap, ga, ca, gp, cp))
+    assert gap <= 1e-4, (gpu_losses, cpu_losses)
+    assert len(set(round(v, 6) for v in gpu_losses)) == steps  # the draws differ from step to step
+    assert abs(ga - ca) <= 1e-3 and abs(gp - cp) <= 1e-3
