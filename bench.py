@@ -64,7 +64,7 @@ BASE_DRUG, BASE_DIS, BASE_EDGES, KNN_K = 100_000, 50_000, 10_000_000, 64
 # scale_rows (diag(cj) X, one streaming pass) + gather kernel (unweighted) + the 8-plane reduce (dst scale).  Its time
 # is taken with HIP events around the three; rocprofv3's averages of the kernels add up to it.
 # 50k-source direction: 32-lane groups; 100k-source direction: 16-lane groups, two column passes (dgmi_sliced.hip)
-DOMINANT = "scale_rows_kernel<4> + spmm_sliced_vec4_kernel<{32|16},false,false,false,true> + reduce_planes_kernel<true,8>"
+DOMINANT = "scale_rows_kernel<4> + spmm_sliced_vec4_kernel<{32|16},0,false,false,true> + reduce_planes_kernel<true,8>"
 
 
 def algorithmic_bytes(nnz, n_rows, weighted, n_scales_src=0, n_scales_dst=0, width=F):

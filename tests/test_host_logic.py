@@ -309,6 +309,17 @@ def test_edge_dropout_is_a_mask_view_with_the_same_product(selection):
         assert torch.equal(both.keep_mask(), m) and 0 < int(m.sum()) < base.nnz // 2
         ref_ab = ops.CSRGraph(base._S.dst, base._S.src, nd, nd, vals=base._coo_vals * m)
         assert torch.allclose(both.spmm(x), ref_ab.spmm(x), atol=1e-6)
+        # masked(m).dropped(d) must carry the values masked() multiplied its mask into — a dropout
+        # of that view (random_edge_dropout_sparse: survivors() is not None -> undropped().masked(...)) starts from the
+        # ORIGINAL weights, never from unit weights
+        m0 = (torch.rand(base.nnz) < 0.8).float()
+        md = base.masked(m0).dropped(d_a)
+        assert md._vals_before_mask is base._coo_vals and torch.equal(md.undropped()._coo_vals, base._coo_vals)
+        again = G.random_edge_dropout_sparse(md, 0.5, as_view=True)
+        alive = again.survivors()
+        assert bool((alive <= m0 * ops.keep_mask(d_a, base.nnz)).all()) and int(alive.sum()) == max(1, int(int((m0 * ops.keep_mask(d_a, base.nnz)).sum()) * 0.5))
+        ref_again = ops.CSRGraph(base._S.dst, base._S.src, nd, nd, vals=base._coo_vals * alive)
+        assert torch.allclose(again.spmm(x), ref_again.spmm(x), atol=1e-6)  # the adjacency's own weights, not ones
 
 
 def test_complement_form_on_a_block_diagonal_union():

@@ -22,6 +22,7 @@ import subprocess
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
+write_traffic = "--no-traffic" not in sys.argv[3:]  # side profiles (the edge-dropped step) must not replace traffic.json
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -66,7 +67,8 @@ with open(os.path.join(out, tag + "_pmc_summary.csv"), "w", newline="") as fh:
 
 # dominant products (GCMC, unweighted, source-scaled): the 50k-source direction runs the 32-lane form, the
 # 100k-source direction the 16-lane form (two column passes: grid.y) — average them by launch count
-main = [r for r in rows if r["kernel"].startswith(("spmm_sliced_vec4_kernel<32, false, false, false",
+main = [r for r in rows if r["kernel"].startswith(("spmm_sliced_vec4_kernel<32, 0, false, false", "spmm_sliced_vec4_kernel<16, 0, false, false",
+                                                   "spmm_sliced_vec4_kernel<32, false, false, false",   # (rounds 1-3: bool HAS_VALS)
                                                    "spmm_sliced_vec4_kernel<16, false, false, false"))]
 red = [r for r in rows if r["kernel"].startswith("reduce_planes_kernel<true")]
 pre = [r for r in rows if r["kernel"].startswith("scale_rows_kernel")]  # the row-scale pass ahead of the gather
@@ -92,7 +94,7 @@ def git_head():
         return None
 
 
-if dom:
+if dom and write_traffic:
     n = sum(r["launches"] for r in main)
     wavg = lambda key: (sum((r[key] or 0) * r["launches"] for r in main) / n) if all(r[key] is not None for r in main) else None
     req = {"gather_kernel": {k: wavg(k) for k in ("RDREQ_avg", "RDREQ_DRAM_avg", "RDREQ_32B_avg", "WRREQ_avg", "WRREQ_DRAM_avg", "WRREQ_64B_avg")},
