@@ -17,11 +17,12 @@
 #include <stdint.h>
 
 #include "dgmi_kernels.h"
+#include "dgmi_tuning.h"
 
 namespace dgmi {
 namespace {
 
-constexpr int kSortThreads = 1024;                    // 16 waves, one workgroup per CU (LDS-bound)
+constexpr int kSortThreads = 1024;                    // 16 waves; two workgroups per CU (68 KB of LDS each at 9-bit digits)
 constexpr int kSortWaves = kSortThreads / 64;
 constexpr int kItems = 8;                             // records per thread
 constexpr int kTile = kSortThreads * kItems;          // 8192 records per workgroup
@@ -30,7 +31,20 @@ constexpr int kMaxBuckets = 1 << kMaxDigitBits;
 
 struct SortPass {
   int shift, bits;  // digit = (key >> shift) & ((1 << bits) - 1)
+  int per_xcd;      // > 0: XCD-aware tile order — block b takes tile (b % 8) * per_xcd + b / 8 (see tile_of)
 };
+
+// Which tile a workgroup takes.  A digit's run of tile t is followed, in the output, by the same digit's run of tile t + 1,
+// and a run is ~16 records = 64 B at an arbitrary offset: most 128-B lines of the output are shared by the runs of two
+// CONSECUTIVE tiles.  Workgroups are dealt round-robin over the 8 XCDs, so with tile = blockIdx.x the two halves of such a
+// line are written from two different (non-coherent, write-back) L2s and reach memory as two partial writes.  With
+// per_xcd = ceil(n_tiles / 8), XCD x works through the contiguous tile range [x * per_xcd, (x + 1) * per_xcd) in order:
+// the neighbouring runs meet in ONE L2 and leave it as whole lines.  Placement is a speed assumption only.
+__device__ __forceinline__ int tile_of(const SortPass& ps, int n_tiles) {
+  if (ps.per_xcd <= 0) return (int)blockIdx.x;
+  const int t = (int)(blockIdx.x & 7u) * ps.per_xcd + (int)(blockIdx.x >> 3);
+  return t < n_tiles && (int)(blockIdx.x >> 3) < ps.per_xcd ? t : -1;
+}
 
 // tile histogram of one pass: hist[bucket * n_tiles + tile]
 template <bool FIRST>
@@ -39,28 +53,26 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const int32_t* 
                                                                  int32_t n_rows, int32_t n_cols, int32_t* __restrict__ flag) {
   __shared__ int cnt[kMaxBuckets];
   const int nb = 1 << ps.bits;
+  const int tile = tile_of(ps, n_tiles);
+  if (tile < 0) return;  // block-uniform
   for (int b = threadIdx.x; b < nb; b += kSortThreads) cnt[b] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * kTile;
+  const int64_t base = (int64_t)tile * kTile;
   bool bad = false;
 #pragma unroll
   for (int k = 0; k < kItems; ++k) {
     const int64_t i = base + (int64_t)k * kSortThreads + threadIdx.x;  // any order: a histogram
     if (i < E) {
       const int32_t key = keys[i];
-      if (FIRST) {  // the id range check rides on the first read of the edge list
-        if (n_rows > 0) bad |= (key < 0) | (key >= n_rows);
-        if (n_cols > 0) {
-          const int32_t c = col[i];
-          bad |= (c < 0) | (c >= n_cols);
-        }
-      }
+      if (FIRST && n_rows > 0) bad |= (key < 0) | (key >= n_rows);  // the row-id range check rides on the first read of the
+                                                                    // keys; the column ids are checked where they are first read
+                                                                    // anyway: the first scatter (80 -> 40 MB for this launch)
       atomicAdd(&cnt[((uint32_t)key >> ps.shift) & (uint32_t)(nb - 1)], 1);
     }
   }
   if (FIRST && bad) *flag = 1;  // benign race: every writer stores the same value
   __syncthreads();
-  for (int b = threadIdx.x; b < nb; b += kSortThreads) hist[(int64_t)b * n_tiles + blockIdx.x] = cnt[b];
+  for (int b = threadIdx.x; b < nb; b += kSortThreads) hist[(int64_t)b * n_tiles + tile] = cnt[b];
 }
 
 // Exclusive scan of hist[bucket][tile] in bucket-major order, in place, as two small launches (one workgroup per
@@ -121,19 +133,21 @@ template <bool FIRST>
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const int32_t* __restrict__ keys_in, const int32_t* __restrict__ eid_in,
                                                                     const int32_t* __restrict__ col_in, int64_t E, SortPass ps, int n_tiles,
                                                                     const int32_t* __restrict__ offs, int32_t* __restrict__ keys_out,
-                                                                    int32_t* __restrict__ eid_out, int32_t* __restrict__ col_out) {
+                                                                    int32_t* __restrict__ eid_out, int32_t* __restrict__ col_out,
+                                                                    int32_t n_cols, int32_t* __restrict__ flag) {
   extern __shared__ int32_t lds[];
-  int32_t* s_key = lds;                    // [kTile] records in digit order
-  int32_t* s_eid = lds + kTile;
-  int32_t* s_col = lds + 2 * kTile;
-  int32_t* cnt = lds + 3 * kTile;          // [kSortWaves][nb] per-wave digit counts, then exclusive over waves
+  int32_t* s_buf = lds;                    // [kTile] ONE field of the records in digit order (key, then eid, then col:
+                                           // 32 KB instead of 96 KB of staging -> two workgroups per CU, whose phases overlap)
+  int32_t* cnt = lds + kTile;              // [kSortWaves][nb] per-wave digit counts, then exclusive over waves
   const int nb = 1 << ps.bits;
   int32_t* dstart = cnt + kSortWaves * nb; // [nb] first LDS slot of a digit in this tile
   int32_t* gbase = dstart + nb;            // [nb] global position of the tile's first record of a digit
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = tile_of(ps, n_tiles);
+  if (tile < 0) return;  // block-uniform
   for (int i = threadIdx.x; i < kSortWaves * nb; i += kSortThreads) cnt[i] = 0;
   __syncthreads();
-  const int64_t tile0 = (int64_t)blockIdx.x * kTile;
+  const int64_t tile0 = (int64_t)tile * kTile;
   const int64_t wave0 = tile0 + (int64_t)wave * (kItems * 64);  // a wave owns 512 CONSECUTIVE records: 8 rounds of 64
   int32_t key[kItems], eid[kItems], col[kItems], rank[kItems];
   uint32_t dig[kItems];
@@ -147,6 +161,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const int32_
     eid[k] = (FIRST && eid_in == nullptr) ? (int32_t)i : (ok ? eid_in[i] : 0);
     col[k] = ok ? col_in[i] : 0;
     dig[k] = ((uint32_t)key[k] >> ps.shift) & (uint32_t)(nb - 1);
+    if (FIRST && n_cols > 0 && ((col[k] < 0) | (col[k] >= n_cols))) *flag = 1;  // benign race: every writer stores the same value
   }
 #pragma unroll
   for (int k = 0; k < kItems; ++k) {
@@ -163,46 +178,76 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const int32_
     if (ok && (m & lt) == 0ull) my_cnt[dig[k]] = before + __popcll(m);
   }
   __syncthreads();
-  // per digit: exclusive prefix over the waves (in place), the tile's count, its global base
-  for (int d = threadIdx.x; d < nb; d += kSortThreads) {
+  // per digit (one thread each: nb <= 512 <= the workgroup): exclusive prefix over the waves (in place), the tile's count,
+  // its global base — then the digit's first slot in the tile = exclusive scan of the counts over the digits, done by
+  // the whole workgroup (wave scans + the waves' totals).  A single thread walking the 512 counts with dependent LDS
+  // reads held the other 1023 threads at the barrier for most of the kernel's time: rounds 1-3, 95 us per 10 M-record pass.
+  __shared__ int wtot[kSortWaves];
+  int my_count = 0;
+  if ((int)threadIdx.x < nb) {
+    const int d = threadIdx.x;
     int run = 0;
     for (int w = 0; w < kSortWaves; ++w) {
       const int c = cnt[w * nb + d];
       cnt[w * nb + d] = run;
       run += c;
     }
-    dstart[d] = run;  // count for now
-    gbase[d] = offs[(int64_t)d * n_tiles + blockIdx.x];
+    my_count = run;
+    gbase[d] = offs[(int64_t)d * n_tiles + tile];
+  }
+  int incl = my_count;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int y = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += y;
+  }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  if ((int)threadIdx.x < nb) {
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wtot[w];
+    dstart[threadIdx.x] = before + incl - my_count;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {  // exclusive scan of <= 512 counts: the digit's first slot in the tile
-    int run = 0;
-    for (int d = 0; d < nb; ++d) {
-      const int c = dstart[d];
-      dstart[d] = run;
-      run += c;
-    }
-  }
-  __syncthreads();
+  int slot[kItems];
 #pragma unroll
   for (int k = 0; k < kItems; ++k) {
-    if (wave0 + k * 64 + lane < E) {
-      const int slot = dstart[dig[k]] + my_cnt[dig[k]] + rank[k];
-      s_key[slot] = key[k];
-      s_eid[slot] = eid[k];
-      s_col[slot] = col[k];
-    }
+    slot[k] = dstart[dig[k]] + my_cnt[dig[k]] + rank[k];
+    if (wave0 + k * 64 + lane < E) s_buf[slot[k]] = key[k];
   }
   __syncthreads();
   const int64_t left = E - tile0;
   const int n_here = left < kTile ? (int)left : kTile;
-  for (int i = threadIdx.x; i < n_here; i += kSortThreads) {  // consecutive slots of one digit -> consecutive addresses
-    const int32_t k2 = s_key[i];
-    const uint32_t d = ((uint32_t)k2 >> ps.shift) & (uint32_t)(nb - 1);
-    const int64_t pos = (int64_t)gbase[d] + (i - dstart[d]);
-    keys_out[pos] = k2;
-    eid_out[pos] = s_eid[i];
-    col_out[pos] = s_col[i];
+  int32_t pos[kItems];  // global position of slot threadIdx.x + k * kSortThreads (E <= INT32_MAX)
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {  // consecutive slots of one digit -> consecutive addresses
+    const int i = threadIdx.x + k * kSortThreads;
+    if (i < n_here) {
+      const int32_t k2 = s_buf[i];
+      const uint32_t d = ((uint32_t)k2 >> ps.shift) & (uint32_t)(nb - 1);
+      pos[k] = gbase[d] + (i - dstart[d]);
+      keys_out[pos[k]] = k2;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kItems; ++k)
+    if (wave0 + k * 64 + lane < E) s_buf[slot[k]] = eid[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const int i = threadIdx.x + k * kSortThreads;
+    if (i < n_here) eid_out[pos[k]] = s_buf[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kItems; ++k)
+    if (wave0 + k * 64 + lane < E) s_buf[slot[k]] = col[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kItems; ++k) {
+    const int i = threadIdx.x + k * kSortThreads;
+    if (i < n_here) col_out[pos[k]] = s_buf[i];
   }
 }
 
@@ -255,18 +300,20 @@ hipError_t radix_sort_records(const int32_t* key, const int32_t* eid_in, const i
   const int32_t* ein = eid_in;
   const int32_t* cin = col;
   for (int p = 0; p < passes; ++p) {
-    const SortPass ps{plan.shift[p], plan.bits[p]};
+    const int per_xcd = tuning().sort_plain_tiles ? 0 : (n_tiles + 7) / 8;
+    const SortPass ps{plan.shift[p], plan.bits[p], per_xcd};
+    const unsigned n_blocks = per_xcd > 0 ? (unsigned)(8 * per_xcd) : (unsigned)n_tiles;
     const int nb = 1 << ps.bits;
     const bool last = p == passes - 1;
     int32_t* kout = last ? keys_out : buf[p & 1][0];
     int32_t* eout = last ? eid_out : buf[p & 1][1];
     int32_t* cout = last ? col_out : buf[p & 1][2];
-    const size_t lds = (size_t)(3 * kTile + kSortWaves * nb + 2 * nb) * sizeof(int32_t);
+    const size_t lds = (size_t)(kTile + kSortWaves * nb + 2 * nb) * sizeof(int32_t);
     if (p == 0) {
-      hipLaunchKernelGGL((sort_hist_kernel<true>), dim3((unsigned)n_tiles), dim3(kSortThreads), 0, s, kin, E, ps, n_tiles, hist, col,
+      hipLaunchKernelGGL((sort_hist_kernel<true>), dim3(n_blocks), dim3(kSortThreads), 0, s, kin, E, ps, n_tiles, hist, col,
                          n_rows, n_cols, flag);
     } else {
-      hipLaunchKernelGGL((sort_hist_kernel<false>), dim3((unsigned)n_tiles), dim3(kSortThreads), 0, s, kin, E, ps, n_tiles, hist, col,
+      hipLaunchKernelGGL((sort_hist_kernel<false>), dim3(n_blocks), dim3(kSortThreads), 0, s, kin, E, ps, n_tiles, hist, col,
                          n_rows, n_cols, flag);
     }
     hipLaunchKernelGGL(sort_bucket_totals_kernel, dim3((unsigned)nb), dim3(kSortThreads), 0, s, hist, n_tiles, totals);
@@ -275,12 +322,12 @@ hipError_t radix_sort_records(const int32_t* key, const int32_t* eid_in, const i
       auto kern = sort_scatter_kernel<true>;
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(kSortThreads), lds, s, kin, ein, cin, E, ps, n_tiles, hist, kout, eout, cout);
+      hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kSortThreads), lds, s, kin, ein, cin, E, ps, n_tiles, hist, kout, eout, cout, n_cols, flag);
     } else {
       auto kern = sort_scatter_kernel<false>;
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3((unsigned)n_tiles), dim3(kSortThreads), lds, s, kin, ein, cin, E, ps, n_tiles, hist, kout, eout, cout);
+      hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(kSortThreads), lds, s, kin, ein, cin, E, ps, n_tiles, hist, kout, eout, cout, n_cols, flag);
     }
     kin = kout;
     ein = eout;

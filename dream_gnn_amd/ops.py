@@ -496,16 +496,18 @@ class CSRGraph:
         c = self._c.get(name)
         if c is None:
             if mult is not None:
-                c = sliced.compacted(self._keep, None, indices=mult[1], id_mult=True)
+                c = sliced.compacted(self._keep, None, indices=mult[2], id_mult=True)
             else:
                 c = sliced.compacted(self._keep, self._vals_for(name, sliced.eid))
             self._c[name] = c
         return c
 
     def _mult_form(self):
-        """``(row_scale[n_dst], code_coo[nnz])`` when this view's edge values are ``row_scale[dst] * m``, ``m`` an
-        integer in 1..8 (``code = m - 1``, COO order) — the reference's ``normalize(adj + adj.T + I)`` adjacencies — else
-        None.  Decided once per weighted graph (shared by its dropped views): one kernel + one host readback."""
+        """``(kind, scale, code_coo[nnz])`` when this view's edge values are ``scale[node] * m`` with ``m`` an integer in
+        1..8 (``code = m - 1``, COO order), else None.  ``kind == "row"``: ``scale`` is indexed by the destination (row)
+        — the reference's ``normalize(adj + adj.T + I)`` adjacencies, ``D^-1 M``; ``kind == "col"``: by the source
+        (column) — the TRANSPOSE of such an adjacency handed in as a graph of its own (``M D^-1``).  Decided once per
+        weighted graph (shared by its dropped views): one kernel + one host readback per form tried."""
         if self._coo_vals is None or not MULT_FORM or self._S.n_src > MULT_MAX_IDS or self._S.n_dst > MULT_MAX_IDS:
             return None
         m = self._v.get("mult")
@@ -513,25 +515,35 @@ class CSRGraph:
             if torch.cuda.is_current_stream_capturing():
                 return None  # the decision needs a readback: not inside a capture (the value stream is always right)
             S = self._S
+            m = False
             scale, code, fail = _T.row_multiplicity(S.indptr, self.vals, MULT_REL_TOL)
-            if int(fail.item()) != 0:
-                m = False
-            else:
+            if int(fail.item()) == 0:
                 code_coo = torch.empty_like(code)
                 code_coo[S.eid.long()] = code
-                m = (scale, code_coo)
+                m = ("row", scale, code_coo)
+            else:
+                indptr_t, _, vals_t, _ = self.transposed()
+                scale, code, fail = _T.row_multiplicity(indptr_t, vals_t, MULT_REL_TOL)
+                if int(fail.item()) == 0:
+                    code_coo = torch.empty_like(code)
+                    code_coo[S.t[2].long()] = code
+                    m = ("col", scale, code_coo)
             self._v["mult"] = m
         return m or None
 
     def _mult_ids(self, name: str, sliced: "SlicedCSR"):
-        """``(row_scale, id words of layout `name` with the multiplicities in bits 28..30)`` or None."""
+        """``(kind, scale, id words of layout `name` with the multiplicities in bits 28..30)`` or None."""
         mf = self._mult_form()
         if mf is None:
             return None
         ids = self._v.get(name + "/ids")
         if ids is None:
-            ids = self._v[name + "/ids"] = sliced.indices | (mf[1][sliced.eid.long()] << MULT_SHIFT)
-        return mf[0], ids
+            ids = self._v[name + "/ids"] = sliced.indices | (mf[2][sliced.eid.long()] << MULT_SHIFT)
+        return mf[0], mf[1], ids
+
+    @staticmethod
+    def _fold(scale, other):
+        return scale if other is None else scale * other.reshape(-1)
 
     def _vals_for(self, layout: str, eid: torch.Tensor):
         if self._coo_vals is None:
@@ -651,13 +663,16 @@ class CSRGraph:
             if S.sliced is None:
                 S.sliced = SlicedCSR.from_csr(S.indptr, S.indices, S.eid, S.n_dst, S.n_src)  # one partition pass, no sort
             mult = self._mult_ids("sliced", S.sliced)
-            if mult is not None:  # values = row scale x multiplicity: the scale is a destination scale here
-                dst_scale = mult[0] if dst_scale is None else mult[0] * dst_scale.reshape(-1)
+            if mult is not None:  # values = scale x multiplicity: a destination (D^-1 M) or a source (M D^-1) scale
+                if mult[0] == "row":
+                    dst_scale = self._fold(mult[1], dst_scale)
+                else:
+                    src_scale = self._fold(mult[1], src_scale)
             c = self._compacted("sliced", S.sliced, mult)
             if c is not None:
                 return c.spmm(X, src_scale, dst_scale, out, epi=epi)
             if mult is not None:
-                return S.sliced.spmm(X, src_scale, dst_scale, out, vals=None, keep=self._keep, epi=epi, indices=mult[1], id_mult=True)
+                return S.sliced.spmm(X, src_scale, dst_scale, out, vals=None, keep=self._keep, epi=epi, indices=mult[2], id_mult=True)
             return S.sliced.spmm(X, src_scale, dst_scale, out, vals=self._vals_for("sliced", S.sliced.eid), keep=self._keep,
                                  epi=epi)
         if X.dim() == 2 and self._use_split(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
@@ -682,13 +697,16 @@ class CSRGraph:
             if S.sliced_t is None:
                 S.sliced_t = SlicedCSR.from_csr(indptr_t, indices_t, eid_t, S.n_src, S.n_dst)
             mult = self._mult_ids("sliced_t", S.sliced_t)
-            if mult is not None:  # A^T = M^T diag(row scale): the scale multiplies the gathered (destination-node) rows
-                dst_scale = mult[0] if dst_scale is None else mult[0] * dst_scale.reshape(-1)
+            if mult is not None:  # (D^-1 M)^T = M^T D^-1: the scale multiplies the gathered (destination-node) rows; (M D^-1)^T: the output rows
+                if mult[0] == "row":
+                    dst_scale = self._fold(mult[1], dst_scale)
+                else:
+                    src_scale = self._fold(mult[1], src_scale)
             c = self._compacted("sliced_t", S.sliced_t, mult)
             if c is not None:
                 return c.spmm(dY, dst_scale, src_scale, out)
             if mult is not None:
-                return S.sliced_t.spmm(dY, dst_scale, src_scale, out, vals=None, keep=self._keep, indices=mult[1], id_mult=True)
+                return S.sliced_t.spmm(dY, dst_scale, src_scale, out, vals=None, keep=self._keep, indices=mult[2], id_mult=True)
             return S.sliced_t.spmm(dY, dst_scale, src_scale, out, vals=self._vals_for("sliced_t", S.sliced_t.eid),
                                    keep=self._keep)
         if dY.dim() == 2 and self._use_split(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):

@@ -194,11 +194,11 @@ def test_full_model_gradients_of_both_forms_against_an_f64_evaluation(oracle, de
     compared with each other (HIP vs CPU-oracle path) the complement form looked 60x worse on the parameters whose
     gradient is a near-total cancellation over all nodes (1.7e-2 vs 2.7e-4 of the tensor's max on TGCN.0.basis).
     Against an evaluation of the whole model in float64 (CPU, torch double, float64 SpMM) both forms are held to the SAME
-    bounds: 1e-4 of the tensor's maximum for every GCMC-channel weight (TGCN.*.att / basis / ufc.weight — where the forms
-    differ), 1e-3 for everything else (bias gradients are cancelling sums over every node / pair: 6e-4 on
-    TGCN.0.ufc.bias at the merged shape in the PLAIN form; FGCN.gc1 sits behind a relu whose sign flips under fp32
-    rounding: 7e-4 already between MKL fp32 and float64 on the CPU) — and the complement form may not be worse than the
-    plain one by more than rounding noise (3x, or 1e-4)."""
+    bounds — at lrssl shape 1e-4 of the tensor's maximum for every GCMC-channel weight (TGCN.*.att / basis / ufc.weight:
+    where the forms differ) and 1e-3 for everything else (bias gradients are cancelling sums over every node / pair;
+    FGCN.gc1 sits behind a relu whose sign flips under fp32 rounding: 7e-4 already between MKL fp32 and float64 on the
+    CPU) — and, tensor by tensor, the complement form may not be worse than the plain one by more than rounding noise
+    (1.5x, or 1e-4)."""
     from dream_gnn_amd import synth
 
     blocks = [synth.DATASET_SHAPES["lrssl"]] if blocks_name == "lrssl" else [synth.DATASET_SHAPES["Cdataset"], synth.DATASET_SHAPES["Gdataset"]]
@@ -214,12 +214,17 @@ def test_full_model_gradients_of_both_forms_against_an_f64_evaluation(oracle, de
         worst[complement] = {k: float((g[k] - g64[k]).abs().max()) / max(float(g64[k].abs().max()), 1e-30) for k in g64}
     top = lambda d: sorted(((round(e, 7), k) for k, e in d.items() if k.startswith("TGCN.")), reverse=True)[:4]
     print("%s: worst TGCN gradient errors vs f64 — plain %s; complement %s" % (blocks_name, top(worst[False]), top(worst[True])))
+    # lrssl shape: 1e-4 on the GCMC-channel weights (measured 4.2e-5 / 4.4e-5), 1e-3 elsewhere.  Merged C+G shape (two
+    # blocks, 256-d): fp32 itself is further from float64 there — the PLAIN form errs by 3.6e-3 on TGCN.1.basis (a sum over
+    # 1 978 nodes x 256 columns that cancels almost completely) and 6e-4 on TGCN.0.ufc.bias, the complement form by the same
+    # 3.6e-3 / 6e-4 — so the absolute bound is 5e-3 there and the statement that matters is the relative one below.
+    tight, loose = (1e-4, 1e-3) if blocks_name == "lrssl" else (5e-3, 5e-3)
     for complement in (False, True):
         for k, e in worst[complement].items():
-            tight = k.startswith("TGCN.") and not k.endswith(".bias")
-            assert e <= (1e-4 if tight else 1e-3), (("complement" if complement else "plain"), k, e)
-    for k, e in worst[True].items():
-        assert e <= max(3.0 * worst[False][k], 1e-4), ("complement form worse than the plain one", k, e, worst[False][k])
+            is_weight = k.startswith("TGCN.") and not k.endswith(".bias")
+            assert e <= (tight if is_weight else loose), (("complement" if complement else "plain"), k, e)
+    for k, e in worst[True].items():  # the complement form is as accurate as the plain one, tensor by tensor
+        assert e <= max(1.5 * worst[False][k], 1e-4), ("complement form worse than the plain one", k, e, worst[False][k])
 
 
 def _module_parity_runs(dev, blocks, out_units, seed, res, H, M, synth):
@@ -271,27 +276,19 @@ def _module_parity(dev, blocks, out_units, seed, complement=False):
     # parameter gradients pass through 3 layers of fp32 GEMMs whose reduction order differs between
     # hipBLASLt and MKL; bias gradients are cancelling sums over every node / pair (worst measured:
     # 2.7e-4 of the tensor's max on TGCN.2.ufc.bias at the merged shape)
-    # Complement form (f3): the label-0 relation enters as `column sum - complement`, so every destination row of a
-    # layer shares ONE rounding of that column sum (a 763-term fp32 sum, ~1e-7 relative) instead of carrying its own.
-    # The two boxes round it differently (HIP kernel order vs MKL); a shift common to all rows does not average out over
-    # the nodes the way independent per-row roundings do, and the parameters whose gradient is a near-total
-    # cancellation over all nodes (TGCN.0.basis: max 2e-3 here) see it: measured 1.7e-2 of the tensor's max, against
-    # 2.7e-4 in the plain form.  Both are fp32 evaluations of equal accuracy — against an f64 evaluation of one layer the
-    # two forms' gradients err by 8e-7 and 1.1e-6 of the max (tools/complement_check.py), and against an f64 evaluation of
-    # the WHOLE model both meet the same bounds (test_full_model_gradients_of_both_forms_against_an_f64_evaluation: 4.2e-5 /
-    # 4.4e-5 on the worst TGCN tensor at lrssl shape) — so the bound between the two fp32 evaluations is looser here,
-    # the forward (loss, logits) is held to the same 1e-5 / 1e-4 as the plain form.
-    tol = 5e-2 if complement else 1e-3
+    # (The COMPLEMENT form is not compared here: two fp32 evaluations that round one shared column sum differently sit
+    # 1.7e-2 apart on TGCN.0.basis while each is within 4.4e-5 of an f64 evaluation — both forms are held to the same
+    # bounds against float64 in test_full_model_gradients_of_both_forms_against_an_f64_evaluation instead.)
+    tol = 1e-3
     for k in cg:
         scale = float(cg[k].abs().max())
         assert float((gg[k] - cg[k]).abs().max()) <= tol * scale + 1e-9, (k, scale)
 
 
-@pytest.mark.parametrize("complement", [False, True])
-def test_cfg2_lrssl_full_model_hip_vs_cpu_oracle_path(oracle, dev, complement):
+def test_cfg2_lrssl_full_model_hip_vs_cpu_oracle_path(oracle, dev):
     from dream_gnn_amd import synth
 
-    _module_parity(dev, [synth.DATASET_SHAPES["lrssl"]], 128, seed=0, complement=complement)
+    _module_parity(dev, [synth.DATASET_SHAPES["lrssl"]], 128, seed=0)
 
 
 def test_cfg3_c_plus_g_merged_full_model_hip_vs_cpu_oracle_path(oracle, dev):

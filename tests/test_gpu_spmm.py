@@ -960,7 +960,10 @@ def test_row_multiplicity_finds_the_reference_adjacency_form_and_only_that(dev):
     vals_csr = g.vals.cpu().numpy()
     assert np.all(np.abs((code + 1) * scale[rows] - vals_csr) <= 2.4e-7 * vals_csr)
     mf = g._mult_form()
-    assert mf is not None and torch.equal(mf[1][g.eid.long()].cpu(), torch.from_numpy(code))
+    assert mf is not None and mf[0] == "row" and torch.equal(mf[2][g.eid.long()].cpu(), torch.from_numpy(code))
+    gt = ops.CSRGraph(t(c), t(r), n, n, vals=t(v))  # the transpose handed in as a graph of its own: M D^-1, a COLUMN scale
+    mft = gt._mult_form()
+    assert mft is not None and mft[0] == "col" and torch.equal(mft[1], mf[1]) and torch.equal(mft[2], mf[2])
     for name, v2 in (("random", rng.uniform(0.1, 1.0, v.size).astype(np.float32)),
                      ("one zero", np.where(np.arange(v.size) == 17, 0.0, v).astype(np.float32)),
                      ("one negative", np.where(np.arange(v.size) == 17, -v, v).astype(np.float32)),
@@ -1000,6 +1003,12 @@ def test_weighted_product_without_a_value_stream_equals_the_weighted_product(ora
     t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
     g = ops.CSRGraph(t(r), t(c), n, n, vals=t(v))
     assert g._mult_form() is not None
+    # the transposed adjacency as a graph of its own (column-scale form): its product is the first graph's transpose product
+    gt = ops.CSRGraph(t(c), t(r), n, n, vals=t(v))
+    assert gt._mult_form()[0] == "col"
+    assert float((gt.spmm(t(W), t(ds), t(ss)) - g.spmm_t(t(W), t(ss), t(ds))).abs().max()) <= 2e-6 * float(g.spmm_t(t(W), t(ss), t(ds)).abs().max())
+    assert float((gt.spmm_t(t(X), t(ds), t(ss)) - g.spmm(t(X), t(ss), t(ds))).abs().max()) <= 2e-6 * float(g.spmm(t(X), t(ss), t(ds)).abs().max())
+    assert "sliced" not in gt._v and "sliced_t" not in gt._v
     keep_n = int(E * 0.9)
     desc = ops.random_subset_select(E, keep_n, 7, dev)
     full = np.ones(E, bool)

@@ -4,7 +4,7 @@ replaced are in profiles/r03_csr_build/ (measured in the same process while both
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from dream_gnn_amd import ops
+from dream_gnn_amd import _lib, ops
 dev = torch.device("cuda:0")
 gen = torch.Generator(device=dev).manual_seed(1)
 
@@ -22,11 +22,16 @@ for n_rows, n_cols, E in ((50_000, 100_000, 10_000_000), (100_000, 50_000, 10_00
     col = torch.randint(0, n_cols, (E,), generator=gen, device=dev, dtype=torch.int32)
     own = ops.csr_from_coo(row, col, n_rows, n_cols, return_flag=True)
     t_own = t(lambda: ops.csr_from_coo(row, col, n_rows, n_cols))
+    _lib.set_tuning("sort_plain_tiles", 1)  # A/B: tile = blockIdx.x (rounds 1-3) against the XCD-aware tile order
+    plain = ops.csr_from_coo(row, col, n_rows, n_cols)
+    t_plain = t(lambda: ops.csr_from_coo(row, col, n_rows, n_cols))
+    _lib.set_tuning("sort_plain_tiles", 0)
+    assert all(torch.equal(a, b) for a, b in zip(own[:3], plain))
     order = torch.sort(row.long(), stable=True).indices
     ref_ptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
     ref_ptr[1:] = torch.cumsum(torch.bincount(row.long(), minlength=n_rows), 0)
     same = torch.equal(own[0].long(), ref_ptr) and torch.equal(own[1], col[order]) and torch.equal(own[2].long(), order)
-    line = "%9d rows %9d edges: CSR %.3f ms" % (n_rows, E, t_own)
+    line = "%9d rows %9d edges: CSR %.3f ms (plain tile order %.3f)" % (n_rows, E, t_own, t_plain)
     if n_rows * 8 < 2**31 and E > 0:
         sl = ops.SlicedCSR(row, col, n_rows, n_cols)
         sl2 = ops.SlicedCSR.from_csr(own[0], own[1], own[2], n_rows, n_cols)
