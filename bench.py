@@ -252,8 +252,8 @@ def cpu_baseline(torch, ops, budget_s=12.0):
 
 def n1_reference():
     """N = 1 throughput to quote speed-ups against inside an N > 1 run: the committed bench line of this round
-    (profiles/r03_bench.json), else round 2's."""
-    for name in ("r03_bench.json", "r02_bench.json"):
+    (profiles/r04_bench.json), else an earlier round's."""
+    for name in ("r04_bench.json", "r03_bench.json", "r02_bench.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 line = json.load(f)
