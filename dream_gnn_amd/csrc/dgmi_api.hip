@@ -37,7 +37,6 @@ Tuning& tuning() {
     v.select_window_min = env_ll("DGMI_SELECT_WINDOW_MIN", 0);
     v.select_narrow_window = env_ll("DGMI_SELECT_NARROW_WINDOW", 0) != 0 ? 1 : 0;
     v.sort_plain_tiles = env_ll("DGMI_SORT_PLAIN_TILES", 0) != 0 ? 1 : 0;
-    v.compact_multi_launch = env_ll("DGMI_COMPACT_MULTI_LAUNCH", 0) != 0 ? 1 : 0;
     return v;
   }();
   return t;
@@ -58,7 +57,6 @@ DGMI_API int dgmi_set_tuning(const char* name, int64_t value) {
   else if (strcmp(name, "select_window_min") == 0) t.select_window_min = value;
   else if (strcmp(name, "select_narrow_window") == 0) t.select_narrow_window = value != 0;
   else if (strcmp(name, "sort_plain_tiles") == 0) t.sort_plain_tiles = value != 0;
-  else if (strcmp(name, "compact_multi_launch") == 0) t.compact_multi_launch = value != 0;
   else return DGMI_ERR_INVALID_ARG;
   return DGMI_OK;
 }

@@ -13,9 +13,6 @@
 //   K2  scan      exclusive scan of the tile counts (one workgroup)
 //   K3  scatter   kept ids (and values) move to their rank; rank at every 64-position word kept  reads/writes ids
 //   K4  pointers  ptr_out[k] = rank(ptr[k])                                                      reads ptr
-// K1-K3 also exist as ONE launch (compact_fused_kernel): a tile's workgroup flags, publishes its count, obtains the
-// number of survivors before it by decoupled look-back over its predecessors' published counts, and scatters — the hash
-// (ALU-bound) of one tile overlaps the copies of another, and two launches and the bit-mask round trip disappear.
 //
 // ~116 MB of streaming traffic for a 10 M-edge layout (HBM-bound integer work), after which the products run the
 // plain kernels — no eid stream, no hash, column passes as usual — over 10 % fewer edges, and sum the kept edges
@@ -25,7 +22,6 @@
 
 #include "dgmi_keep.h"
 #include "dgmi_kernels.h"
-#include "dgmi_tuning.h"
 
 namespace dgmi {
 namespace {
@@ -42,12 +38,7 @@ struct Workspace {
   int32_t* tile_count;  // n_tiles
   int32_t* tile_off;    // n_tiles + 1 (exclusive scan; last = number of survivors)
   int32_t* word_rank;   // n_words: survivors before the word's first position
-  uint64_t* status;     // fused form: [0] ticket counter, [1] error flag, [2 + t] tile t's (count << 2) | state
 };
-
-constexpr int kStatusHeader = 2;
-constexpr unsigned long long kStateAggregate = 1ull, kStatePrefix = 2ull;  // 0: nothing published yet
-constexpr int kSpinLimit = 1 << 22;  // bounded wait (seconds): a predecessor always runs — tiles are taken by ticket
 
 inline int64_t n_tiles_of(int64_t nnz) { return (nnz + kTile - 1) / kTile; }
 inline int64_t n_words_of(int64_t nnz) { return n_tiles_of(nnz) * kWordsPerTile; }  // whole tiles: no bounds tests on words
@@ -64,12 +55,8 @@ Workspace carve(void* base, int64_t nnz) {
   w.tile_off = reinterpret_cast<int32_t*>(p);
   p += align256((size_t)(n_tiles_of(nnz) + 1) * sizeof(int32_t));
   w.word_rank = reinterpret_cast<int32_t*>(p);
-  p += align256((size_t)n_words_of(nnz) * sizeof(int32_t));
-  w.status = reinterpret_cast<uint64_t*>(p);
   return w;
 }
-
-inline size_t status_bytes(int64_t nnz) { return (size_t)(kStatusHeader + n_tiles_of(nnz)) * sizeof(uint64_t); }
 
 // K1: one ballot per 64 positions; wave w of the block owns words w, w + 4, ... of the tile, so a lane's 8 eid loads
 // are independent, coalesced 256-B rows.
@@ -191,126 +178,19 @@ __global__ __launch_bounds__(kThreads) void compact_scatter_kernel(const int32_t
   }
 }
 
-// K1 + K2 + K3 in one launch.  Tiles are taken by TICKET (an atomic counter), so the tile a workgroup waits for was
-// taken by a workgroup that is already running: the look-back cannot wait on work that has not started.  status[t] packs
-// the state with the value (one 64-bit relaxed agent-scope store / load each: nothing else to order).  The wait is bounded
-// anyway: on exhaustion the error word is set, and K4 then writes an EMPTY layout (all pointers 0) instead of a wrong one.
-template <bool HAS_VALS>
-__global__ __launch_bounds__(kThreads) void compact_fused_kernel(const int32_t* __restrict__ eid, const int32_t* __restrict__ indices,
-                                                                 const float* __restrict__ vals, int64_t nnz,
-                                                                 const KeepSeg* __restrict__ keep, int n_keep,
-                                                                 uint64_t* __restrict__ status, uint64_t* __restrict__ bits,
-                                                                 int32_t* __restrict__ word_rank, int32_t* __restrict__ indices_out,
-                                                                 float* __restrict__ vals_out) {
-  __shared__ unsigned long long sb[kWordsPerTile];
-  __shared__ int sr[kWordsPerTile];
-  __shared__ int wave_cnt[kThreads / 64];
-  __shared__ int s_tile;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) s_tile = (int)atomicAdd(reinterpret_cast<unsigned long long*>(status), 1ull);
-  __syncthreads();
-  const int tile = s_tile;
-  const int64_t base = (int64_t)tile * kTile;
-  int32_t e[kPerThread], id[kPerThread];
-  float v[kPerThread];
-#pragma unroll
-  for (int j = 0; j < kPerThread; ++j) {
-    const int64_t p = base + j * kThreads + threadIdx.x;
-    e[j] = p < nnz ? eid[p] : 0;
-    id[j] = p < nnz ? indices[p] : 0;
-    if (HAS_VALS) v[j] = p < nnz ? vals[p] : 0.f;
-  }
-  int cnt = 0;
-#pragma unroll
-  for (int j = 0; j < kPerThread; ++j) {
-    const int64_t p = base + j * kThreads + threadIdx.x;
-    const bool k = p < nnz && edge_kept(keep, n_keep, (uint32_t)e[j]);
-    const unsigned long long m = __ballot(k);
-    if (lane == 0) sb[j * (kThreads / 64) + wave] = m;
-    cnt += __popcll(m);
-  }
-  if (lane == 0) wave_cnt[wave] = cnt;
-  __syncthreads();
-  if (wave == 0) {
-    const int agg = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    uint64_t* st = status + kStatusHeader;
-    if (lane == 0)
-      __hip_atomic_store(st + tile, ((unsigned long long)agg << 2) | (tile == 0 ? kStatePrefix : kStateAggregate), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    int prefix = 0;
-    if (tile > 0) {
-      int look = tile - 1, spins = 0;
-      while (true) {  // 64 predecessors per round, nearest first (lane 0)
-        const int idx = look - lane;
-        const unsigned long long w = idx >= 0 ? __hip_atomic_load(st + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kStatePrefix;
-        const unsigned long long f = w & 3ull;
-        const unsigned long long ready = __ballot(f != 0ull), have = __ballot(f == kStatePrefix);
-        const int first = have ? __ffsll(have) - 1 : 64;  // nearest predecessor that knows its inclusive prefix
-        const unsigned long long need = first >= 63 ? ~0ull : ((2ull << first) - 1ull);
-        if ((ready & need) != need) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > kSpinLimit) {
-            if (lane == 0) atomicOr(reinterpret_cast<unsigned long long*>(status + 1), 1ull);
-            break;
-          }
-          continue;
-        }
-        int c = lane <= first ? (int)(w >> 2) : 0;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-        prefix += c;
-        if (first < 64) break;
-        look -= 64;
-      }
-      if (lane == 0)
-        __hip_atomic_store(st + tile, ((unsigned long long)(prefix + agg) << 2) | kStatePrefix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const unsigned long long wbits = sb[lane & (kWordsPerTile - 1)];
-    int incl = lane < kWordsPerTile ? __popcll(wbits) : 0;
-    const int own = incl;
-#pragma unroll
-    for (int d = 1; d < kWordsPerTile; d <<= 1) {
-      const int u = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += u;
-    }
-    if (lane < kWordsPerTile) {
-      const int r = prefix + incl - own;
-      sr[lane] = r;
-      word_rank[(base >> 6) + lane] = r;
-      bits[(base >> 6) + lane] = wbits;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < kPerThread; ++j) {
-    const int word = j * (kThreads / 64) + wave;
-    const unsigned long long w = sb[word];
-    if ((w >> lane) & 1ull) {
-      const int out = sr[word] + __popcll(w & ((1ull << lane) - 1ull));
-      indices_out[out] = id[j];
-      if (HAS_VALS) vals_out[out] = v[j];
-    }
-  }
-}
-
 // K4: where every row / segment boundary lands.
 __global__ __launch_bounds__(kThreads) void compact_ptr_kernel(const int32_t* __restrict__ ptr, int64_t n_ptr, int64_t nnz,
                                                                const uint64_t* __restrict__ bits,
                                                                const int32_t* __restrict__ word_rank,
                                                                const int32_t* __restrict__ tile_off, int64_t n_tiles,
-                                                               const uint64_t* __restrict__ status, int32_t* __restrict__ ptr_out) {
+                                                               int32_t* __restrict__ ptr_out) {
   const int64_t stride = (int64_t)gridDim.x * kThreads;
-  // fused form: the number of survivors is the last tile's inclusive prefix; a look-back that gave up -> an empty layout
-  const bool failed = status != nullptr && status[1] != 0ull;
-  const int total = status != nullptr ? (int)(status[kStatusHeader + n_tiles - 1] >> 2) : tile_off[n_tiles];
   for (int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x; k < n_ptr; k += stride) {
     int64_t q = ptr[k];
     if (q < 0) q = 0;  // a meaningless layout (range flag set at its build) stays in bounds
     int r;
-    if (failed) {
-      r = 0;
-    } else if (q >= nnz) {
-      r = total;
+    if (q >= nnz) {
+      r = tile_off[n_tiles];
     } else {
       const int64_t w = q >> 6;
       r = word_rank[w] + __popcll(bits[w] & ((1ull << (q & 63)) - 1ull));
@@ -329,7 +209,7 @@ __global__ void zero_i32_kernel(int32_t* p, int64_t n) {
 size_t compact_workspace_bytes(int64_t nnz) {
   const int64_t nt = n_tiles_of(nnz), nw = n_words_of(nnz);
   return align256((size_t)nw * sizeof(uint64_t)) + align256((size_t)nt * sizeof(int32_t)) +
-         align256((size_t)(nt + 1) * sizeof(int32_t)) + align256((size_t)nw * sizeof(int32_t)) + align256(status_bytes(nnz)) + 256;
+         align256((size_t)(nt + 1) * sizeof(int32_t)) + align256((size_t)nw * sizeof(int32_t)) + 256;
 }
 
 hipError_t compact_layout_i32(const int32_t* ptr, int64_t n_ptr, const int32_t* indices, const float* vals, const int32_t* eid,
@@ -343,21 +223,6 @@ hipError_t compact_layout_i32(const int32_t* ptr, int64_t n_ptr, const int32_t* 
   }
   const Workspace w = carve(workspace, nnz);
   const int64_t nt = n_tiles_of(nnz);
-  int64_t pb = (n_ptr + kThreads - 1) / kThreads;
-  if (pb > 4096) pb = 4096;
-  if (!tuning().compact_multi_launch) {
-    hipError_t err = hipMemsetAsync(w.status, 0, status_bytes(nnz), s);
-    if (err != hipSuccess) return err;
-    if (vals != nullptr)
-      hipLaunchKernelGGL(compact_fused_kernel<true>, dim3((unsigned)nt), dim3(kThreads), 0, s, eid, indices, vals, nnz,
-                         static_cast<const KeepSeg*>(keep), n_keep, w.status, w.bits, w.word_rank, indices_out, vals_out);
-    else
-      hipLaunchKernelGGL(compact_fused_kernel<false>, dim3((unsigned)nt), dim3(kThreads), 0, s, eid, indices, vals, nnz,
-                         static_cast<const KeepSeg*>(keep), n_keep, w.status, w.bits, w.word_rank, indices_out, vals_out);
-    hipLaunchKernelGGL(compact_ptr_kernel, dim3((unsigned)pb), dim3(kThreads), 0, s, ptr, n_ptr, nnz, w.bits, w.word_rank, w.tile_off,
-                       nt, w.status, ptr_out);
-    return hipGetLastError();
-  }
   hipLaunchKernelGGL(compact_flag_kernel, dim3((unsigned)nt), dim3(kThreads), 0, s, eid, nnz, static_cast<const KeepSeg*>(keep),
                      n_keep, w.bits, w.tile_count);
   hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, w.tile_count, nt, w.tile_off);
@@ -367,8 +232,10 @@ hipError_t compact_layout_i32(const int32_t* ptr, int64_t n_ptr, const int32_t* 
   else
     hipLaunchKernelGGL(compact_scatter_kernel<false>, dim3((unsigned)nt), dim3(kThreads), 0, s, indices, vals, nnz, w.bits,
                        w.tile_off, w.word_rank, indices_out, vals_out);
+  int64_t pb = (n_ptr + kThreads - 1) / kThreads;
+  if (pb > 4096) pb = 4096;
   hipLaunchKernelGGL(compact_ptr_kernel, dim3((unsigned)pb), dim3(kThreads), 0, s, ptr, n_ptr, nnz, w.bits, w.word_rank, w.tile_off,
-                     nt, static_cast<const uint64_t*>(nullptr), ptr_out);
+                     nt, ptr_out);
   return hipGetLastError();
 }
 

@@ -14,7 +14,6 @@ struct Tuning {
   int64_t sliced_chunk_rows = 0;    // DGMI_SLICED_CHUNK_ROWS: destination rows per launch pair
   int64_t select_window_min = 0;    // DGMI_SELECT_WINDOW_MIN: shortest list that takes the window passes
   int select_narrow_window = 0;     // DGMI_SELECT_NARROW_WINDOW: a window that misses (forces the take-over path; test)
-  int compact_multi_launch = 0;     // DGMI_COMPACT_MULTI_LAUNCH: layout compaction as flag / scan / scatter launches (A/B of the fused form)
   int sort_plain_tiles = 0;         // DGMI_SORT_PLAIN_TILES: record sort with tile = blockIdx.x instead of the XCD-aware order
 };
 

@@ -27,28 +27,18 @@ def timeit(fn, reps=30, warm=5):
     return a.elapsed_time(b) / reps * 1e3
 
 
-from dream_gnn_amd import _lib
-
 drug, dis = synth.bipartite_edges(100_000, 50_000, 10_000_000, seed=0, device=dev)
 sl = O.SlicedCSR(dis, drug, 50_000, 100_000)
 desc = O.random_subset_select(10_000_000, 9_000_000, 5, dev)
+us = timeit(lambda: sl.compacted(desc))
+print("bipartite 10 M edges, sliced layout (400 001 pointers), unweighted: %.1f us = %.2f TB/s of the 12 B/edge it must move"
+      % (us, 10e6 * 11.6 / us / 1e6), flush=True)
 r, c, v = synth.knn_sim_graph(100_000, 64, 21, dev)
 sk = O.SlicedCSR(r, c, 100_000, 100_000, vals=v)
 dk = O.random_subset_select(int(r.numel()), int(r.numel() * 0.9), 6, dev)
+us = timeit(lambda: sk.compacted(dk, sk.vals))
+print("kNN-64 %d nnz, sliced layout, weighted: %.1f us = %.2f TB/s of the 19.2 B/edge it must move" % (r.numel(), us, r.numel() * 19.2 / us / 1e6), flush=True)
 g = O.CSRGraph(dis, drug, 50_000, 100_000)
-ref = None
-for multi in (0, 1, 0, 1):  # fused (one chained-scan launch + pointers) against flag / scan / scatter / pointers
-    _lib.set_tuning("compact_multi_launch", multi)
-    tag = "4 launches" if multi else "fused     "
-    c1 = sl.compacted(desc)
-    if ref is None:
-        ref = c1
-    assert torch.equal(c1.segptr, ref.segptr) and torch.equal(c1.indices[:9_000_000], ref.indices[:9_000_000])
-    us = timeit(lambda: sl.compacted(desc))
-    print("%s bipartite 10 M edges, sliced layout (400 001 pointers), unweighted: %.1f us = %.2f TB/s of the 11.6 B/edge it must move"
-          % (tag, us, 10e6 * 11.6 / us / 1e6), flush=True)
-    us = timeit(lambda: sk.compacted(dk, sk.vals))
-    print("%s kNN-64 %d nnz, sliced layout, weighted: %.1f us = %.2f TB/s of the 19.2 B/edge it must move" % (tag, r.numel(), us, r.numel() * 19.2 / us / 1e6), flush=True)
-    us = timeit(lambda: _lib.torch_ops.compact_layout(g.indptr, g.indices, None, g.eid, desc.reshape(1, 8)))
-    print("%s bipartite 10 M edges, plain CSR (50 001 pointers): %.1f us" % (tag, us), flush=True)
-_lib.set_tuning("compact_multi_launch", 0)
+from dream_gnn_amd import _lib
+us = timeit(lambda: _lib.torch_ops.compact_layout(g.indptr, g.indices, None, g.eid, desc.reshape(1, 8)))
+print("bipartite 10 M edges, plain CSR (50 001 pointers): %.1f us" % us, flush=True)
