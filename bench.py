@@ -79,6 +79,17 @@ def compulsory_bytes(nnz, n_rows, n_src, weighted, n_scales_src=0, n_scales_dst=
         + 4 * n_scales_src + 4 * n_scales_dst
 
 
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """One line on stderr (rank 0 / the single process): a long N > 1 run — graph generation for 8 x config 4, two
+    workloads — must not look hung to whoever watches its output."""
+    if os.environ.get("RANK", "0") == "0":
+        sys.stderr.write("[bench.py %7.1f s] %s\n" % (time.perf_counter() - _T0, msg))
+        sys.stderr.flush()
+
+
 def timeit(torch, fn, reps=30, warm=5):
     """Average ms per call by HIP events on the current stream."""
     for _ in range(warm):
@@ -691,6 +702,7 @@ def main():
 
     __graft_entry__.ensure_built()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL / device-tensor sharing needs on this stack
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: be one.  Nothing in this process has touched the GPU (torch is not even imported yet).
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
@@ -788,9 +800,12 @@ def main():
             out["predicted_speedup"] = {f: round(edges / (v * 1e-3) / n1["value"], 3) for f, v in out["predicted_ms_per_step"].items()}
         return out
 
+    progress("building the workload (%d rank%s)" % (world, "" if world == 1 else "s, %s-scaled" % args.scale))
     ops, build_ms, (nd, ns, E, knn_k) = build_ops(torch, rank, world, dev, args.scale if world > 1 else "edges")
+    progress("workload built: bipartite %dx%d, %d edges + kNN-%d; timing %d + %d steps" % (nd, ns, E, knn_k, args.warmup, args.steps))
     exchange, exchange_timing = pick_exchange(ops)
     elapsed, edges_per_step = measure(ops, args.steps, args.warmup, exchange=exchange)
+    progress("timed region done: %.3f ms per step" % (elapsed / args.steps * 1e3))
     primary_reading = reading(ops, elapsed, edges_per_step, args.steps, exchange) if world > 1 else None
 
     # per-kernel HIP-event time on the launch stream (rank 0's launches)
@@ -840,6 +855,7 @@ def main():
         del ops
         torch.cuda.empty_cache()
         ops2 = None
+        progress("building the %s-scaled workload" % alt)
         try:  # a rank that cannot build its shards must not leave the others inside a collective
             ops2, _, (nd2, ns2, E2, k2) = build_ops(torch, rank, world, dev, alt)
         except Exception as exc:  # noqa: BLE001
@@ -848,6 +864,7 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok.item()) > 0:
             el2, edges2 = measure(ops2, args.steps, args.warmup, exchange=exchange)
+            progress("%s-scaled reading done: %.3f ms per step" % (alt, el2 / args.steps * 1e3))
             other = {"workload": "bipartite %dx%d, %d edges + kNN-%d" % (nd2, ns2, E2, k2),
                      "value": edges2 * args.steps / el2, "unit": "edges/s",
                      "steps": args.steps, "edges_per_step": int(edges2)}
@@ -928,6 +945,7 @@ def main():
         if other is not None:
             out["edge_scaled" if args.scale == "nodes" else "node_scaled"] = other
         if world == 1 and not args.no_variants:
+            progress("variants, edge-dropped step, model steps (context beside the judged step)")
             try:  # extra products beside the judged step: a failure here must not cost the line
                 out["variants"] = variants(torch, dev, ops)
             except Exception as exc:  # noqa: BLE001
@@ -938,6 +956,7 @@ def main():
                 out["edge_dropped_step"] = {"error": repr(exc)}
             out["model_steps"] = model_steps_in_child()
         if world == 1 and not args.no_cpu_baseline:
+            progress("cpu_baseline (bounded sample on the host cores)")
             try:
                 out["cpu_baseline"] = cpu_baseline(torch, ops)
             except Exception as exc:  # noqa: BLE001

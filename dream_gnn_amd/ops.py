@@ -440,6 +440,7 @@ class CSRGraph:
         view._keep = self._keep
         view._mask = keep if self._mask is None else self._mask * keep
         view._vals_before_mask = self._vals_before_mask if self._mask is not None else self._coo_vals
+        view._v["mult"] = False  # zeros among the values: no scale x multiplicity form — and no per-step detection (a readback)
         return view
 
     def dropped(self, desc: torch.Tensor) -> "CSRGraph":
