@@ -453,7 +453,7 @@ DGMI_API int dgmi_compact_layout_i32(const int32_t* ptr, int64_t n_ptr, const in
                                      const int32_t* eid, int64_t nnz, const uint32_t* keep, int32_t n_keep, int32_t* ptr_out,
                                      int32_t* indices_out, float* vals_out, void* workspace, size_t workspace_bytes,
                                      dgmi_stream_t stream) {
-  if (n_ptr < 0 || nnz < 0 || n_keep < 0 || n_keep > dgmi::kMaxKeepSegs || (n_keep > 0 && keep == nullptr))
+  if (n_ptr < 0 || nnz < 0 || n_keep < 1 || n_keep > dgmi::kMaxKeepSegs || keep == nullptr)  // nothing dropped: nothing to compact
     return DGMI_ERR_INVALID_ARG;
   if (nnz > INT32_MAX || n_ptr > INT32_MAX) return DGMI_ERR_TOO_LARGE;
   if (n_ptr == 0) return DGMI_OK;

@@ -33,12 +33,36 @@ constexpr int kMaxKeepSegs = 8;
 constexpr uint32_t kKeepInvert = 1u;
 constexpr uint32_t kDroppedBit = 0x80000000u;  // flag carried in the sign bit of a source id
 
+// hash32(seed, e): two 32-bit avalanche rounds (the murmur3 finaliser, then the "lowbias32" mixer), keyed with one half
+// of the 64-bit seed each.  For a fixed seed it is a BIJECTION of the 32-bit edge id, so the E keys of a list are distinct
+// and the threshold's tie rule is only ever exercised by the tests.  Four 32-bit multiplies: rounds 2-3 used the splitmix64
+// finaliser (eleven, quarter-rate on this chip), which made every pass that hashes — the selection's two window passes, the
+// compaction's flag pass, the on-the-fly KEEP kernels — ALU-bound (compaction flag pass 25 -> 12 us per 10 M edges).
 __device__ __forceinline__ uint32_t edge_hash(uint64_t seed, uint64_t e) {
-  uint64_t z = seed + (e + 1) * 0x9E3779B97F4A7C15ull;  // splitmix64 finaliser
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  uint32_t x = (uint32_t)e ^ (uint32_t)seed;
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  x += (uint32_t)(seed >> 32);
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+
+// Does segment `sg` let edge e take part?  (Edges it does not cover: yes.)
+__device__ __forceinline__ bool seg_lets(const KeepSeg& sg, uint32_t e) {
+  if (e >= sg.e_begin && e < sg.e_end) {
+    const uint32_t local = e - sg.e_begin;
+    const uint32_t h = edge_hash(((uint64_t)sg.seed_hi << 32) | sg.seed_lo, local);
+    const bool in_subset = h < sg.thr || (h == sg.thr && (int32_t)local <= sg.tie_cut);
+    if (in_subset == ((sg.flags & kKeepInvert) != 0u)) return false;
+  }
+  return true;
 }
 
 // Edges outside every segment are kept; an edge covered by several segments (a dropout applied to an
@@ -47,12 +71,20 @@ __device__ __forceinline__ uint32_t edge_hash(uint64_t seed, uint64_t e) {
 __device__ __forceinline__ bool edge_kept(const KeepSeg* __restrict__ tab, int n_seg, uint32_t e) {
   for (int k = 0; k < n_seg; ++k) {
     const KeepSeg sg = tab[k];
-    if (e >= sg.e_begin && e < sg.e_end) {
-      const uint32_t local = e - sg.e_begin;
-      const uint32_t h = edge_hash(((uint64_t)sg.seed_hi << 32) | sg.seed_lo, local);
-      const bool in_subset = h < sg.thr || (h == sg.thr && (int32_t)local <= sg.tie_cut);
-      if (in_subset == ((sg.flags & kKeepInvert) != 0u)) return false;
-    }
+    if (!seg_lets(sg, e)) return false;
+  }
+  return true;
+}
+
+// The same with the FIRST description already in registers (`first = tab[0]`, loaded once per wave before its edge loop
+// — wave-uniform, so it lives in SGPRs): almost every product has exactly one description, and reading the table per
+// edge cost three DEPENDENT scalar loads per item (e_begin, then e_end, then the rest: the compiler sinks the loads into
+// the range tests), each behind a full s_waitcnt.
+__device__ __forceinline__ bool edge_kept(const KeepSeg& first, const KeepSeg* __restrict__ tab, int n_seg, uint32_t e) {
+  if (!seg_lets(first, e)) return false;
+  for (int k = 1; k < n_seg; ++k) {
+    const KeepSeg sg = tab[k];
+    if (!seg_lets(sg, e)) return false;
   }
   return true;
 }

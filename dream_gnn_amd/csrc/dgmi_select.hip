@@ -324,8 +324,13 @@ __global__ __launch_bounds__(kSelectThreads) void window_finalize_kernel(BatchPa
 __global__ __launch_bounds__(kBlock) void keep_mask_kernel(const KeepSeg* __restrict__ tab, int n_seg, int64_t E,
                                                            float* __restrict__ mask) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
+  if (n_seg <= 0) {
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += stride) mask[e] = 1.f;
+    return;
+  }
+  const KeepSeg first = tab[0];
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += stride)
-    mask[e] = edge_kept(tab, n_seg, (uint32_t)e) ? 1.f : 0.f;
+    mask[e] = edge_kept(first, tab, n_seg, (uint32_t)e) ? 1.f : 0.f;
 }
 
 inline unsigned grid_for(int64_t n) {

@@ -134,6 +134,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
   const int32_t* sp = segptr + (int64_t)slice * n_dst + row0;
   float* prow = planes + ((int64_t)slice * (row_end - row_begin) + (row0 - row_begin)) * ldp + col;
 
+  const KeepSeg first = first_seg<KEEP>(keep);
   const int my_b = sp[glane < nr ? glane : nr];  // lane k holds boundary k (k <= nr)
   const int e_begin = __shfl(my_b, gbase, kWave);
   const int e_end = __shfl(my_b, gbase + nr, kWave);
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
   int last_row = -1;  // KEEP: the row this group gathered last (where a dropped edge's load is parked)
   if (e_begin < e_end) {
     const int q = e_begin + glane < e_end ? e_begin + glane : e_begin;
-    nxt_idx = fetch_id<KEEP>(indices, eid, keep, n_keep, q);
+    nxt_idx = fetch_id<KEEP>(indices, eid, first, keep, n_keep, q);
     if (W_LANE) {
       nxt_w = HAS_VALS ? vals[q] : 1.f;
       if (HAS_SS) nxt_w *= src_scale[(KEEP || MULT) ? nxt_idx & kIdMask : nxt_idx];
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
     if (base + LPR < e_end) {
       const int nb = base + LPR;
       const int q = nb + glane < e_end ? nb + glane : nb;
-      nxt_idx = fetch_id<KEEP>(indices, eid, keep, n_keep, q);
+      nxt_idx = fetch_id<KEEP>(indices, eid, first, keep, n_keep, q);
       if (W_LANE) {
         nxt_w = HAS_VALS ? vals[q] : 1.f;
         if (HAS_SS) nxt_w *= src_scale[(KEEP || MULT) ? nxt_idx & kIdMask : nxt_idx];

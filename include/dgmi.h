@@ -367,6 +367,7 @@ DGMI_API int dgmi_row_multiplicity_f32(const int32_t* indptr, const float* vals,
  * kernels over the compacted layout (n_keep = 0): no eid stream, no hash per edge and pass — at 10 M edges an
  * edge-dropped product costs 19-27 % more than the un-dropped one on the fly, and less than it after compaction.
  * workspace: dgmi_compact_layout_workspace_bytes(nnz) bytes, 8-B aligned.  vals and vals_out: both or neither.
+ * 1 <= n_keep <= 8 (a layout nothing was dropped from needs no copy).
  */
 DGMI_API size_t dgmi_compact_layout_workspace_bytes(int64_t nnz);
 DGMI_API int dgmi_compact_layout_i32(const int32_t* ptr, int64_t n_ptr, const int32_t* indices, const float* vals,

@@ -240,19 +240,28 @@ def similarity_graph_coo(sim, k, symm=True):
 
 
 def _edge_hash(seed, E):
-    """hash32(seed, e) for e in [0, E): the splitmix64 finaliser of dream_gnn_amd/csrc/dgmi_keep.h."""
-    with np.errstate(over="ignore"):
-        e = np.arange(E, dtype=np.uint64)
-        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + (e + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    return (z >> np.uint64(32)).astype(np.uint64)
+    """hash32(seed, e) for e in [0, E): restatement of ``edge_hash`` in dream_gnn_amd/csrc/dgmi_keep.h — two 32-bit
+    avalanche rounds (murmur3's finaliser, then lowbias32), keyed with the low / high half of the seed; a bijection of
+    the edge id for a fixed seed."""
+    seed &= 0xFFFFFFFFFFFFFFFF
+    m = np.uint64(0xFFFFFFFF)
+    x = (np.arange(E, dtype=np.uint64) ^ np.uint64(seed & 0xFFFFFFFF)) & m  # 32-bit arithmetic carried in uint64
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x85EBCA6B)) & m
+    x ^= x >> np.uint64(13)
+    x = (x * np.uint64(0xC2B2AE35)) & m
+    x ^= x >> np.uint64(16)
+    x = (x + np.uint64(seed >> 32)) & m
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & m
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & m
+    x ^= x >> np.uint64(16)
+    return x
 
 
 def random_subset_mask(E, keep, seed):
-    """Restatement of ``dgmi_random_subset_mask_f32``: keys (hash32(seed, e), e) with the
-    splitmix64 finaliser; the ``keep`` smallest keys are kept.  The subset it stands for is the
+    """Restatement of ``dgmi_random_subset_mask_f32``: keys (hash32(seed, e), e); the ``keep`` smallest keys are kept.  The subset it stands for is the
     reference's ``randperm(E)[:num_keep]`` (augmentation.py:48-52): uniformly random, exact size."""
     h = _edge_hash(seed, E)
     order = np.lexsort((np.arange(E), h))  # by hash, ties by edge id

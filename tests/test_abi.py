@@ -76,7 +76,8 @@ def test_argument_validation_returns_codes_without_a_gpu():
     assert L.dgmi_compact_layout_i32(16, 5, 16, None, 16, 100, None, 1, 16, 16, None, 16, 1 << 20, None) == -1  # keep missing
     assert L.dgmi_compact_layout_i32(16, 5, 16, 16, 16, 100, 16, 1, 16, 16, None, 16, 1 << 20, None) == -1      # vals without vals_out
     assert L.dgmi_compact_layout_i32(16, 5, 16, None, 16, 100, 16, 1, 16, 16, None, 16, 8, None) == -3          # workspace too small
-    assert L.dgmi_compact_layout_i32(None, 0, None, None, None, 0, None, 0, None, None, None, None, 0, None) == 0
+    assert L.dgmi_compact_layout_i32(None, 0, None, None, None, 0, 16, 1, None, None, None, None, 0, None) == 0   # empty layout
+    assert L.dgmi_compact_layout_i32(16, 5, 16, None, 16, 100, None, 0, 16, 16, None, 16, 1 << 20, None) == -1  # nothing dropped
     # launch-parameter overrides: known names only; the library reads no environment on a launch path
     assert L.dgmi_set_tuning(b"sliced_rows", 0) == 0 and L.dgmi_set_tuning(b"no_such_knob", 1) == -1
     assert L.dgmi_set_tuning(None, 1) == -1

@@ -146,3 +146,24 @@ def test_oracle_compaction_equals_the_rebuild_from_the_kept_edges(oracle):
         p, i, v = oracle.compact_layout(sp, si, vals[se], se, table)
         kp, ki, ke = oracle.csr_sliced_from_coo(dst[mask], src[mask], n_dst, n_src, 8)
         assert np.array_equal(p, kp) and np.array_equal(i, ki) and np.array_equal(v, vals[mask][ke])
+
+
+def test_edge_hash_is_a_bijection_and_seeds_give_independent_subsets(oracle):
+    """hash32(seed, e) (csrc/dgmi_keep.h, restated in oracle._edge_hash): distinct keys for distinct edges of one list
+    (a bijection of the 32-bit id), uniform over the 32-bit range, and subsets drawn with different seeds — including
+    seeds that differ in ONE half only, or by 1 — overlap like independent uniform subsets (keep^2 / E, 5 sigma)."""
+    from oracle.oracle import _edge_hash
+
+    E = 1 << 20
+    for seed in (0, 1, 2 ** 62 - 1, 0x123456789ABCDEF):
+        h = _edge_hash(seed, E)
+        assert np.unique(h).size == E
+        assert h.max() < 2 ** 32
+        buckets = np.bincount((h >> np.uint64(24)).astype(np.int64), minlength=256)  # 256 bins of 4096 expected
+        assert abs(buckets - E / 256).max() < 6 * np.sqrt(E / 256)
+    E, keep = 200_000, 100_000
+    base = oracle.random_subset_mask(E, keep, 777).astype(bool)
+    exp, sd = keep * keep / E, np.sqrt(E * 0.25 * 0.25)
+    for other in (778, 777 + (1 << 32), 777 ^ (1 << 40), 12345678901234567, 776):
+        m = oracle.random_subset_mask(E, keep, other).astype(bool)
+        assert abs(int((base & m).sum()) - exp) < 5 * sd, other
