@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kThreads) void compact_flag_kernel(const int32_t* _
     const int64_t p = base + j * kThreads + threadIdx.x;
     e[j] = p < nnz ? eid[p] : 0;
   }
-  const KeepSeg first = keep[0];  // n_keep >= 1 (checked by the ABI): one wide scalar load, not three dependent ones per item
+  const KeepPre first = keep_preload(keep, n_keep);  // n_keep >= 1 (checked by the ABI): wide scalar loads once, not three dependent ones per item
   int cnt = 0;
 #pragma unroll
   for (int j = 0; j < kPerThread; ++j) {

@@ -76,13 +76,25 @@ __device__ __forceinline__ bool edge_kept(const KeepSeg* __restrict__ tab, int n
   return true;
 }
 
-// The same with the FIRST description already in registers (`first = tab[0]`, loaded once per wave before its edge loop
-// — wave-uniform, so it lives in SGPRs): almost every product has exactly one description, and reading the table per
-// edge cost three DEPENDENT scalar loads per item (e_begin, then e_end, then the rest: the compiler sinks the loads into
-// the range tests), each behind a full s_waitcnt.
-__device__ __forceinline__ bool edge_kept(const KeepSeg& first, const KeepSeg* __restrict__ tab, int n_seg, uint32_t e) {
-  if (!seg_lets(first, e)) return false;
-  for (int k = 1; k < n_seg; ++k) {
+// The same with the first TWO descriptions already in registers (loaded once per wave before its edge loop — wave-uniform,
+// so they live in SGPRs): almost every product has one description, the relation-fused aggregates of the real datasets two
+// (one per rating), and reading the table per edge cost three DEPENDENT scalar loads per description (e_begin, then e_end,
+// then the rest: the compiler sinks the loads into the range tests), each behind a full s_waitcnt.
+struct KeepPre {
+  KeepSeg a, b;
+};
+
+__device__ __forceinline__ KeepPre keep_preload(const KeepSeg* __restrict__ tab, int n_seg) {
+  KeepPre p;
+  p.a = tab[0];                      // n_seg >= 1 wherever this is called
+  p.b = tab[n_seg > 1 ? 1 : 0];      // a copy of the first when there is no second: never consulted
+  return p;
+}
+
+__device__ __forceinline__ bool edge_kept(const KeepPre& pre, const KeepSeg* __restrict__ tab, int n_seg, uint32_t e) {
+  if (!seg_lets(pre.a, e)) return false;
+  if (n_seg > 1 && !seg_lets(pre.b, e)) return false;
+  for (int k = 2; k < n_seg; ++k) {
     const KeepSeg sg = tab[k];
     if (!seg_lets(sg, e)) return false;
   }

@@ -135,20 +135,21 @@ __device__ __forceinline__ int compact_live(int& idx, float& w, bool weighted, i
 // is complete (all 64/LPR lane groups combined) in every lane.
 // id of edge q as the gathers will use it: the source id, with (KEEP) kDroppedBit set when
 // keep(eid[q]) says the edge was dropped.
-// `first` = keep[0], loaded once by the caller before its edge loop (dgmi_keep.h: per-edge table reads were three
+// `first` = the first two descriptions, loaded once by the caller before its edge loop (dgmi_keep.h: per-edge table reads were three
 // dependent scalar loads each).
 template <bool KEEP>
 __device__ __forceinline__ int fetch_id(const int32_t* __restrict__ indices, const int32_t* __restrict__ eid,
-                                        const KeepSeg& first, const KeepSeg* __restrict__ keep, int n_keep, int q) {
+                                        const KeepPre& first, const KeepSeg* __restrict__ keep, int n_keep, int q) {
   int idx = indices[q];
   if (KEEP && !edge_kept(first, keep, n_keep, (uint32_t)eid[q])) idx |= (int)kDroppedBit;
   return idx;
 }
 
 template <bool KEEP>
-__device__ __forceinline__ KeepSeg first_seg(const KeepSeg* __restrict__ keep) {
-  if (KEEP) return keep[0];  // KEEP instantiations are only launched with n_keep >= 1
-  return KeepSeg{0u, 0u, 0u, 0u, 0u, -1, 0u, 0u};
+__device__ __forceinline__ KeepPre first_seg(const KeepSeg* __restrict__ keep, int n_keep) {
+  if (KEEP) return keep_preload(keep, n_keep);  // KEEP instantiations are only launched with n_keep >= 1
+  const KeepSeg none{0u, 0u, 0u, 0u, 0u, -1, 0u, 0u};
+  return KeepPre{none, none};
 }
 
 template <int LPR, bool HAS_VALS, bool HAS_SS, bool KEEP>
@@ -161,7 +162,7 @@ __device__ __forceinline__ float4 segment_vec4(const int32_t* __restrict__ indic
                                                int start, int end, int lane) {
   constexpr bool WEIGHTED = HAS_VALS || HAS_SS;
   const int sub = lane / LPR;
-  const KeepSeg first = first_seg<KEEP>(keep);
+  const KeepPre first = first_seg<KEEP>(keep, n_keep);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   // software pipeline: ids (and weights) of batch b+1 are requested before the
   // row loads of batch b are issued.
@@ -222,7 +223,7 @@ __device__ __forceinline__ float segment_dword(const int32_t* __restrict__ indic
                                                const float* __restrict__ Xc, int64_t ldx,
                                                int start, int end, int lane) {
   constexpr bool WEIGHTED = HAS_VALS || HAS_SS;
-  const KeepSeg first = first_seg<KEEP>(keep);
+  const KeepPre first = first_seg<KEEP>(keep, n_keep);
   float acc = 0.f;
   for (int base = start; base < end; base += kWave) {
     int n = min(kWave, end - base);

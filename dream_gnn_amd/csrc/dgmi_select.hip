@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kBlock) void keep_mask_kernel(const KeepSeg* __rest
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += stride) mask[e] = 1.f;
     return;
   }
-  const KeepSeg first = tab[0];
+  const KeepPre first = keep_preload(tab, n_seg);
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < E; e += stride)
     mask[e] = edge_kept(first, tab, n_seg, (uint32_t)e) ? 1.f : 0.f;
 }

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void spmm_sliced_vec4_kernel
   const int32_t* sp = segptr + (int64_t)slice * n_dst + row0;
   float* prow = planes + ((int64_t)slice * (row_end - row_begin) + (row0 - row_begin)) * ldp + col;
 
-  const KeepSeg first = first_seg<KEEP>(keep);
+  const KeepPre first = first_seg<KEEP>(keep, n_keep);
   const int my_b = sp[glane < nr ? glane : nr];  // lane k holds boundary k (k <= nr)
   const int e_begin = __shfl(my_b, gbase, kWave);
   const int e_end = __shfl(my_b, gbase + nr, kWave);
