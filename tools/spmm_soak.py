@@ -39,8 +39,15 @@ for n_dst, n_src, E, F in shapes:
         else:
             dst = torch.randint(0, n_dst, (E,), generator=gen, device=dev, dtype=torch.int32)
         src = torch.randint(0, n_src, (E,), generator=gen, device=dev, dtype=torch.int32)
-        for weighted in (False, True):
-            vals = torch.randn(E, generator=gen, device=dev) if weighted else None
+        for weighted in (False, True, "row scale x multiplicity", "column scale x multiplicity"):
+            if weighted is True:
+                vals = torch.randn(E, generator=gen, device=dev)
+            elif weighted:  # (r4) the reference's adjacency format and its transpose: the value stream is dropped (ops._mult_form)
+                scale = torch.rand(n_dst if weighted.startswith("row") else n_src, generator=gen, device=dev) + 0.05
+                mult = torch.randint(1, 9, (E,), generator=gen, device=dev).float()
+                vals = mult * scale[(dst if weighted.startswith("row") else src).long()]
+            else:
+                vals = None
             g = ops.CSRGraph(dst, src, n_dst, n_src, vals=vals)
             X = torch.randn(n_src, F, generator=gen, device=dev)
             dY = torch.randn(n_dst, F, generator=gen, device=dev)
@@ -58,10 +65,16 @@ for n_dst, n_src, E, F in shapes:
                 keep = int(E * 0.9)
                 desc = ops.random_subset_select(E, keep, 4242 + cases, dev)
                 m = ops.keep_mask(desc, E).bool()
-                yd = g.dropped(desc).spmm(X, a, b)
+                ops.COMPACT_DROPPED = bool(cases % 2)  # (r4) alternate: compacted layouts / on-the-fly KEEP kernels
+                view = g.dropped(desc)
+                yd = view.spmm(X, a, b)
                 ydr = ref(dst[m], src[m], None if vals is None else vals[m], n_dst, n_src, X, a, b)
                 e3 = float((yd.double() - ydr).abs().max() / ydr.abs().max().clamp_min(1e-30))
-                cases += 3
+                dxd = view.spmm_t(dY, a, b)
+                dxr = ref(dst[m], src[m], None if vals is None else vals[m], n_dst, n_src, dY, a, b, transpose=True)
+                e3 = max(e3, float((dxd.double() - dxr).abs().max() / dxr.abs().max().clamp_min(1e-30)))
+                ops.COMPACT_DROPPED = True
+                cases += 4
                 if max(e1, e2, e3) > 2e-5 or int(m.sum()) != keep:
                     bad += 1
                     print("FAIL %s skew=%s weighted=%s scaled=%s: fwd %.2g bwd %.2g dropped %.2g kept %d" %
