@@ -402,10 +402,14 @@ class CSRGraph:
         S.max_deg = S.max_deg_t = None  # longest row of the CSR / of the transposed CSR, once a readback has told
         S.validated = bool(check_range)
         # `regular`: no destination row is extremely long, so the XCD-local kernel (which walks a
-        # (row, slice) segment sequentially) is safe to use.  Known after the one readback below;
-        # False for unchecked builds unless the caller vouches for it (they must not sync).
-        S.regular = bool(regular) if regular is not None else False
-        S.regular_t = regular_t if (regular_t is not None or check_range) else False
+        # (row, slice) segment sequentially) is safe to use.  Known after the one readback of a validated build
+        # (below); for an unchecked build None = not known yet: decided — one readback of the maximum degree — at the
+        # first product LARGE enough for the XCD-local form to be in question (a 4 MB table), never for the small
+        # per-step graphs of the real datasets and never inside a stream capture.  (Until round 4 unchecked builds were
+        # simply "not regular": every adjacency built by graph.similarity_graph / feature_similarity_graph — trusted by
+        # construction — ran the planned kernel at scale, 0.84 ms against 0.41 ms per kNN-64 product.)
+        S.regular = bool(regular) if regular is not None else None
+        S.regular_t = regular_t
         self._set_values(None if vals is None else vals.to(torch.float32).contiguous())
         if check_range:
             # ids are checked BEFORE anything is derived from the CSR: the sort of an edge list with
@@ -513,7 +517,7 @@ class CSRGraph:
             return None
         m = self._v.get("mult")
         if m is None:
-            if torch.cuda.is_current_stream_capturing():
+            if self._capturing():
                 return None  # the decision needs a readback: not inside a capture (the value stream is always right)
             S = self._S
             m = False
@@ -600,6 +604,26 @@ class CSRGraph:
         S.max_deg = int(max_deg)
         S.regular = self._is_regular(int(max_deg), self.nnz, S.n_dst)
 
+    @staticmethod
+    def _capturing() -> bool:
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+    def _decide_regular(self, X, transposed: bool):
+        """Settle ``regular`` / ``regular_t`` of an unchecked build when a product large enough to care arrives."""
+        S = self._S
+        n_cols = S.n_dst if transposed else S.n_src
+        small = X.dim() != 2 or n_cols * X.shape[1] * 4 < min(SLICED_MIN_TABLE_BYTES, SPLIT_MIN_TABLE_BYTES)
+        # a VALIDATED build has synchronised once already and reads the transposed graph's longest row back whatever the
+        # size (it also tells whether the planned form's second launch can be skipped: _plan_if_needed)
+        if (small and not S.validated) or not X.is_cuda or self._capturing():
+            return  # stays unknown (treated as "not regular" for this product): small tables never take the sliced form
+        indptr = self._t_struct()[0] if transposed else S.indptr
+        max_deg = int((indptr[1:] - indptr[:-1]).max()) if self.nnz else 0
+        if transposed:
+            S.max_deg_t, S.regular_t = max_deg, self._is_regular(max_deg, self.nnz, S.n_src)
+        else:
+            S.max_deg, S.regular = max_deg, self._is_regular(max_deg, self.nnz, S.n_dst)
+
     def _use_sliced(self, F: int, n_rows: int, n_cols: int, regular: bool) -> bool:
         if FORCE_KERNEL is not None:  # debugging / A-B aid: DGMI_FORCE_KERNEL=planned|sliced
             return FORCE_KERNEL == "sliced" and F % 4 == 0 and n_rows * SlicedCSR.N_SLICES < 2 ** 31 - 1
@@ -660,6 +684,8 @@ class CSRGraph:
         feature table is a few L2s large and the graph is regular, else the planned kernel.  ``epi``: output epilogue
         (act, slope, out_mask, mask_scale), fused into the kernel that writes the result."""
         S = self._S
+        if S.regular is None:
+            self._decide_regular(X, False)
         if X.dim() == 2 and self._use_sliced(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
             if S.sliced is None:
                 S.sliced = SlicedCSR.from_csr(S.indptr, S.indices, S.eid, S.n_dst, S.n_src)  # one partition pass, no sort
@@ -690,10 +716,8 @@ class CSRGraph:
         """``diag(src_scale) A^T diag(dst_scale) dY`` — the backward of :meth:`spmm`."""
         S = self._S
         indptr_t, indices_t, eid_t, plan_t = self._t_struct()
-        if S.regular_t is None:  # one-time readback of the reversed graph's maximum degree
-            max_deg = int((indptr_t[1:] - indptr_t[:-1]).max()) if self.nnz else 0
-            S.max_deg_t = max_deg
-            S.regular_t = self._is_regular(max_deg, self.nnz, S.n_src)
+        if S.regular_t is None:  # one-time readback of the reversed graph's maximum degree, when it can matter
+            self._decide_regular(dY, True)
         if dY.dim() == 2 and self._use_sliced(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):
             if S.sliced_t is None:
                 S.sliced_t = SlicedCSR.from_csr(indptr_t, indices_t, eid_t, S.n_src, S.n_dst)
@@ -851,7 +875,9 @@ class EdgePairs:
 
     def _group(self, key, n):
         iota = torch.arange(self.E, dtype=torch.int32, device=key.device)
-        g = CSRGraph(key, iota, n, self.E, check_range=False)
+        # every row of the gathered (E, F) matrix is used exactly ONCE (the column ids are a permutation of the edge
+        # ids): no reuse for the XCD-local form to keep in L2 — vouch "not regular" so that it is never chosen
+        g = CSRGraph(key, iota, n, self.E, check_range=False, regular=False, regular_t=False)
         return g
 
     def by_src(self) -> "CSRGraph":

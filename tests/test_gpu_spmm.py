@@ -427,6 +427,20 @@ def test_csrgraph_picks_sliced_only_when_profitable(dev):
     assert not skew.regular and skew._sliced is None and skew._S.split is not None
     ys_plain = ops.spmm_csr_raw(skew.indptr, skew.indices, None, X, plan=skew.plan)
     assert float((ys - ys_plain).abs().max()) <= 1e-5 * float(ys_plain.abs().max())
+    # (r4) an UNCHECKED build (what graph.similarity_graph / feature_similarity_graph hand over: trusted by construction)
+    # learns whether it is regular at its first LARGE product — until round 4 it never took the XCD-local form
+    gu = ops.CSRGraph(dst, src, n_dst, n_src, check_range=False)
+    assert gu.regular is None and gu.regular_t is None
+    gu.spmm(torch.randn(n_src, 16, device=dev))          # 2.5 MB table: nothing to decide, nothing read back
+    assert gu.regular is None and gu._sliced is None
+    assert torch.equal(gu.spmm(X), y) and gu.regular is True and gu._sliced is not None
+    assert torch.equal(gu.spmm_t(W), dx) and gu.regular_t is True and gu._sliced_t is not None
+    su = ops.CSRGraph(skew._S.dst, skew._S.src, n_dst, n_src, check_range=False)
+    assert torch.equal(su.spmm(X), ys_plain) and su.regular is False and su._sliced is None and su._S.split is None  # planned
+    # the decoder's edge-id CSRs never take it: every gathered row is used exactly once
+    pairs = ops.EdgePairs(src[:600_000], dst[:600_000], n_src, n_dst)
+    pairs.by_src().spmm(torch.randn(600_000, 128, device=dev))
+    assert pairs.by_src().regular is False and pairs.by_src()._sliced is None
 
 
 def test_ops_capture_into_a_hip_graph(dev):
