@@ -48,3 +48,17 @@ for drop in (False, True):
     gcmc.train()
     gcn.train()
     print("3 GCMC layers + 2-layer GCN, fwd + bwd, edge dropout %s: %.3f ms per step" % ("on " if drop else "off", wall(lambda: step(drop))), flush=True)
+
+# hidden host synchronisation in the per-step path at scale (a readback per step would serialise host and device)
+import warnings
+torch.cuda.synchronize()
+torch.cuda.set_sync_debug_mode("warn")
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    for _ in range(2):
+        step(True)
+torch.cuda.set_sync_debug_mode("default")
+msgs = ["%s @ %s:%d" % (str(x.message)[:90], x.filename.split("/")[-1], x.lineno) for x in w if "synchron" in str(x.message).lower() and "prototype" not in str(x.message)]
+print("synchronising calls in 2 dropped steps: %d" % len(msgs))
+for m in sorted(set(msgs)):
+    print("  ", msgs.count(m), "x", m)
