@@ -3,7 +3,7 @@
 For each world size and both weak-scaling readings, builds RANK 0's shard of every product exactly as
 bench.py does (bench.build_ops), times the 8 local products on this GPU (per-rank compute: the graph is
 uniform, every rank's shard is statistically the same), and applies DESIGN 6's exchange model
-(dream_gnn_amd.shard.predict_step_seconds) for both exchange forms.  Writes profiles/r03_scale_prediction.json;
+(dream_gnn_amd.shard.predict_step_seconds) for both exchange forms.  Writes profiles/r04_scale_prediction.json;
 bench.py prints the same model's numbers beside the measured ones when it does run on N GPUs.
 """
 import json
@@ -46,6 +46,6 @@ for world in worlds:
         print(json.dumps(entry), flush=True)
         del ops
         torch.cuda.empty_cache()
-with open(os.path.join(ROOT, "gpurun_out", "r03_scale_prediction.json"), "w") as f:  # copied to profiles/ by hand
+with open(os.path.join(ROOT, "gpurun_out", "r04_scale_prediction.json"), "w") as f:  # copied to profiles/ by hand
     json.dump({"gpu": torch.cuda.get_device_name(0), "model": S.predict_step_seconds.__doc__, "link_GBps": S.XGMI_LINK_GBS,
                "links": S.XGMI_LINKS, "rows": rows}, f, indent=1)
