@@ -81,6 +81,15 @@ def test_integration_stub_on_a_random_graph_every_entry_point(oracle, stub, dev,
         assert float(y[5].abs().max()) == 0.0
         y_s = stub["copy_u_sum_xcd_sliced"](t(dst), t(src), n_dst, n_src, x, t(cj), t(ci))
         _vs_oracle(oracle, y_s, ip, ix, None, X, cj, ci, name + ", xcd-sliced")
+    # (r4) the per-iteration edge dropout of train.py:267 through the same raw entry points: select a subset, compact the
+    # CSR — bit-identical to the CSR of the kept edge list — and run the plain product on it
+    ipk, ixk, desc = stub["edge_dropout"](indptr, indices, eid, 0.25, 4242)
+    mask = oracle.keep_mask(desc.cpu().numpy(), E).astype(bool)
+    assert int(mask.sum()) == max(1, int(E * 0.75)) and np.array_equal(desc.cpu().numpy(), oracle.random_subset_select(E, int(mask.sum()), 4242, 0))
+    kp, ki, _ = oracle.csr_from_coo(dst[mask], src[mask], n_dst)
+    assert np.array_equal(ipk.cpu().numpy(), kp) and np.array_equal(ixk.cpu().numpy()[: ki.size], ki)
+    y_k = stub["copy_u_sum"](ipk, ixk, t(X), t(cj), t(ci))
+    _vs_oracle(oracle, y_k, kp, ki, None, X, cj, ci, "edge-dropped, compacted CSR")
     # errors come back as status codes, as the header says: ld < F
     with pytest.raises(RuntimeError, match="invalid argument"):
         stub["check"](stub["lib"].dgmi_spmm_csr_f32(indptr.data_ptr(), indices.data_ptr(), None, None, None, 0, wide.data_ptr(), 4,
