@@ -328,47 +328,111 @@ class _Structure:
 # graphs): a (virtual row, slice) segment is then at most SPLIT_ROW_EDGES / 8 edges long.  A lane group
 # streams 8 consecutive virtual rows of a slice as one dependent chain, so this length sets the critical
 # path of the launch: Zipf(1.2), 10 M edges (tools/zipf_split_probe.py) 0.477 ms at 2048, 0.443 at 1024,
-# 0.418 at 512 (with the launcher's column passes), 0.439 at 256.
-SPLIT_ROW_EDGES = 512
+# 0.418 at 512 (with the launcher's column passes), 0.439 at 256 — in round 2.  Round 4 (tools/zipf_sweep.py, after the
+# touch-ahead and with the light rows out of the sliced pass): 0.374 ms at 512 (23 632 virtual rows: below the 32 768 the
+# launcher wants for its column passes), 0.329 at 256, 0.336 at 192, 0.363 at 128.
+SPLIT_ROW_EDGES = 256
+
+
+# Rows below this many edges do not go through the XCD-local kernel of a split graph at all: a (row, slice) segment of
+# 0-5 edges is all bookkeeping.  A power-law graph is mostly such rows (Zipf(1.2), 10 M edges over 50 000 rows: 42 800 rows
+# hold 5 % of the edges): they are gathered by the second-stage product instead, straight from the source table.
+# tools/zipf_sweep.py, virtual rows of 256 edges: 0.348 ms with every row in the sliced pass, 0.329 / 0.334 / 0.336 with the
+# rows below 24 / 48 / 96 edges out of it.
+SPLIT_LIGHT_ROW_EDGES = 24
 
 
 class _SplitSliced:
-    """XCD-local product for a graph with extremely long rows: every row is cut into virtual rows
-    of at most ``SPLIT_ROW_EDGES`` edges (in CSR order), the sliced kernel runs on the virtual-row
-    graph (regular by construction), and a second, tiny product adds each row's virtual rows back
-    together in order (``Y = C · Yv`` with ``C[row, v] = 1``; ``dst_scale`` applied there)."""
+    """XCD-local product for a graph with extremely long rows.  Every HEAVY row is cut into virtual rows of at most
+    ``SPLIT_ROW_EDGES`` edges (in CSR order), the sliced kernel runs on the virtual-row graph (regular by
+    construction) and writes ``Yv``; a second, small product ``Y = C · [Yv ; Xs]`` then gives every row its sum:
+    ``C[row, v] = 1`` adds a heavy row's virtual rows back together in order, and — **(r4)** when at least a quarter of
+    the rows are LIGHT (< ``SPLIT_LIGHT_ROW_EDGES`` edges) — the light rows' own edges point into the second half of the
+    same table, the (pre-scaled) source rows ``Xs``, so that they never become (row, slice) segments of one or two edges.
+    ``dst_scale`` and the epilogue are applied by that second product."""
 
     def __init__(self, indptr, eid, cols_coo, n_rows, n_cols):
         dev = indptr.device
         nnz = int(eid.shape[0])
         deg = (indptr[1:] - indptr[:-1]).long()
-        nv = torch.clamp((deg + SPLIT_ROW_EDGES - 1) // SPLIT_ROW_EDGES, min=1)
+        light = deg < SPLIT_LIGHT_ROW_EDGES
+        n_light = int(light.sum())  # host syncs here and below: at construction only
+        self.has_light = 4 * n_light >= n_rows and n_light < n_rows
+        if not self.has_light:
+            light = torch.zeros_like(light)
+        nv = torch.where(light, torch.zeros_like(deg), torch.clamp((deg + SPLIT_ROW_EDGES - 1) // SPLIT_ROW_EDGES, min=1))
         vptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
         vptr[1:] = torch.cumsum(nv, 0)
-        self.n_virtual = int(vptr[-1])  # one host sync, at construction only
+        self.n_virtual = int(vptr[-1])
         rows_p = torch.repeat_interleave(torch.arange(n_rows, device=dev), deg, output_size=nnz)
         rank = torch.arange(nnz, device=dev) - indptr.long()[rows_p]
         vrow_p = (vptr[rows_p] + rank // SPLIT_ROW_EDGES).to(torch.int32)
-        vrow_coo = torch.empty(nnz, dtype=torch.int32, device=dev)
-        vrow_coo[eid.long()] = vrow_p  # CSR position -> the caller's edge order
-        self.sliced = SlicedCSR(vrow_coo, cols_coo, self.n_virtual, n_cols)
-        self.c_indptr = vptr.to(torch.int32)
-        self.c_indices = torch.arange(self.n_virtual, dtype=torch.int32, device=dev)
-        self.c_plan = build_plan(self.c_indptr, self.n_virtual)
-        self.n_rows = n_rows
-
-    def spmm(self, X, src_scale, dst_scale, out, vals, keep=None, epi=None, compacted=None):
-        """``compacted``: the virtual-row layout with a view's dropped edges already removed (then ``vals`` / ``keep``
-        are not consulted: it carries its own values)."""
-        if compacted is not None:
-            yv = compacted.spmm(X, src_scale, None, None)
+        cols_p = cols_coo[eid.long()]  # CSR order
+        self.n_rows, self.n_cols = n_rows, n_cols
+        if not self.has_light:
+            vrow_coo = torch.empty(nnz, dtype=torch.int32, device=dev)
+            vrow_coo[eid.long()] = vrow_p  # CSR position -> the caller's edge order
+            self.sliced = SlicedCSR(vrow_coo, cols_coo, self.n_virtual, n_cols)
+            self.c_indptr = vptr.to(torch.int32)
+            self.c_indices = torch.arange(self.n_virtual, dtype=torch.int32, device=dev)
+            self.c_eid = self.c_light_eid = self.c_order = None
         else:
-            yv = self.sliced.spmm(X, src_scale, None, None, vals=vals, keep=keep)
-        F = yv.shape[1]
+            heavy_p = ~light[rows_p]
+            # the heavy rows' edges, in CSR order (a stable sort by (slice, virtual row) keeps it inside a segment); the
+            # layout's eid is composed back to the caller's edge order: values and dropout descriptions index that
+            self.sliced = SlicedCSR(vrow_p[heavy_p].contiguous(), cols_p[heavy_p].contiguous(), self.n_virtual, n_cols)
+            self.sliced.eid = eid[heavy_p][self.sliced.eid.long()].contiguous()
+            # second stage: row r <- its virtual rows (ids < n_virtual) or, for a light row, its own edges (n_virtual + source)
+            light_p = ~heavy_p
+            ent_row = torch.cat([torch.repeat_interleave(torch.arange(n_rows, device=dev), nv, output_size=self.n_virtual), rows_p[light_p]])
+            ent_idx = torch.cat([torch.arange(self.n_virtual, dtype=torch.int32, device=dev), cols_p[light_p] + self.n_virtual])
+            order = torch.sort(ent_row, stable=True).indices
+            self.c_order = order
+            self.c_indices = ent_idx[order].contiguous()
+            cptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+            cptr[1:] = torch.cumsum(torch.where(light, deg, nv), 0)
+            self.c_indptr = cptr.to(torch.int32)
+            self.c_light_eid = eid[light_p]  # the light edges' positions in the caller's order (values, dropout)
+            # edge ids of the second stage's entries for dropout on the fly: virtual-row entries lie outside every description
+            never = torch.full((self.n_virtual,), 0x7FFFFFFF, dtype=torch.int32, device=dev)
+            self.c_eid = torch.cat([never, self.c_light_eid])[order].contiguous()
+        self.c_plan = build_plan(self.c_indptr, int(self.c_indices.shape[0]))
+
+    def combine_values(self, coo_vals):
+        """Values of the second stage's entries for a view with edge values ``coo_vals`` (the caller's order): 1 for a
+        virtual row, the edge's own value for a light row's edge.  None when there is nothing to weight."""
+        if coo_vals is None or not self.has_light:
+            return None
+        ones = torch.ones(self.n_virtual, dtype=torch.float32, device=coo_vals.device)
+        return torch.cat([ones, coo_vals[self.c_light_eid.long()]])[self.c_order].contiguous()
+
+    def spmm(self, X, src_scale, dst_scale, out, vals, keep=None, epi=None, compacted=None, c_vals=None):
+        """``compacted``: the virtual-row layout with a view's dropped edges already removed (then ``vals`` is not
+        consulted: it carries its own values); ``c_vals``: :meth:`combine_values` of the view."""
+        F = X.shape[1]
+        if self.has_light:
+            # [Yv ; Xs] in ONE table: the sliced kernel gathers from its second half and writes its first half
+            buf = torch.empty((self.n_virtual + self.n_cols, F), dtype=torch.float32, device=X.device)
+            xs, yv = buf[self.n_virtual:], buf[:self.n_virtual]
+            if src_scale is not None:
+                torch.mul(X, src_scale.reshape(-1, 1), out=xs)
+            else:
+                xs.copy_(X)
+            if compacted is not None:
+                compacted.spmm(xs, None, None, yv)
+            else:
+                self.sliced.spmm(xs, None, None, yv, vals=vals, keep=keep)
+            table, n_table, c_keep = buf, self.n_virtual + self.n_cols, keep
+        else:
+            if compacted is not None:
+                yv = compacted.spmm(X, src_scale, None, None)
+            else:
+                yv = self.sliced.spmm(X, src_scale, None, None, vals=vals, keep=keep)
+            table, n_table, c_keep = yv, self.n_virtual, None
         if out is None:
-            out = torch.empty((self.n_rows, F), dtype=torch.float32, device=yv.device)
-        return _launch_spmm(yv.device, self.c_indptr, self.c_indices, None, yv, None, dst_scale, out, self.c_plan,
-                            self.n_rows, self.n_virtual, F, F, epi=epi)
+            out = torch.empty((self.n_rows, F), dtype=torch.float32, device=X.device)
+        return _launch_spmm(X.device, self.c_indptr, self.c_indices, c_vals, table, None, dst_scale, out, self.c_plan,
+                            self.n_rows, n_table, F, F, eid=self.c_eid, keep=c_keep, epi=epi)
 
 
 class CSRGraph:
@@ -550,6 +614,15 @@ class CSRGraph:
     def _fold(scale, other):
         return scale if other is None else scale * other.reshape(-1)
 
+    def _combine_vals(self, name: str, split: "_SplitSliced"):
+        """Second-stage values of a split layout for this view's edge values (made once per view and layout)."""
+        if self._coo_vals is None or not split.has_light:
+            return None
+        v = self._v.get(name + "/combine")
+        if v is None:
+            v = self._v[name + "/combine"] = split.combine_values(self._coo_vals)
+        return v
+
     def _vals_for(self, layout: str, eid: torch.Tensor):
         if self._coo_vals is None:
             return None
@@ -708,7 +781,7 @@ class CSRGraph:
             c = self._compacted("split", S.split.sliced)
             return S.split.spmm(X, _prep_scale(src_scale, S.n_src, "src_scale"), _prep_scale(dst_scale, S.n_dst, "dst_scale"),
                                 out, None if c is not None else self._vals_for("split", S.split.sliced.eid), keep=self._keep,
-                                epi=epi, compacted=c)
+                                epi=epi, compacted=c, c_vals=self._combine_vals("split", S.split))
         return self._run(S.indptr, S.indices, self.vals, self._plan_if_needed(S.plan, S.max_deg), S.n_dst, S.n_src, X,
                          src_scale, dst_scale, out, S.eid, epi)
 
@@ -740,7 +813,7 @@ class CSRGraph:
             c = self._compacted("split_t", S.split_t.sliced)
             return S.split_t.spmm(dY, _prep_scale(dst_scale, S.n_dst, "dst_scale"), _prep_scale(src_scale, S.n_src, "src_scale"),
                                   out, None if c is not None else self._vals_for("split_t", S.split_t.sliced.eid), keep=self._keep,
-                                  compacted=c)
+                                  compacted=c, c_vals=self._combine_vals("split_t", S.split_t))
         return self._run(indptr_t, indices_t, self._vals_for("csr_t", eid_t), self._plan_if_needed(plan_t, S.max_deg_t), S.n_src, S.n_dst, dY,
                          dst_scale, src_scale, out, eid_t)
 
