@@ -306,7 +306,8 @@ COMPACT_DROPPED = os.environ.get("DGMI_COMPACT_DROPPED", "1") != "0"
 MULT_FORM = os.environ.get("DGMI_MULT_FORM", "1") != "0"
 MULT_REL_TOL = 2.4e-7
 MULT_SHIFT, MULT_MAX_IDS = 28, 1 << 28
-SPLIT_TIERS = ((48, 600_000_000), (96, 1_000_000_000), (192, 1_800_000_000))
+SPLIT_MIN_DEGREE, SPLIT_DENSE_DEGREE = 8, 300                       # average degree (edges / rows) of the whole graph
+SPLIT_MAX_TABLE_BYTES, SPLIT_MAX_TABLE_BYTES_DENSE = 350_000_000, 900_000_000
 
 
 def _table_cap(tiers, degree: float) -> int:
@@ -710,15 +711,21 @@ class CSRGraph:
         return degree >= lo_deg and lo <= table <= hi
 
     def _use_split(self, F: int, n_rows: int, n_cols: int, regular) -> bool:
-        """Long-row graphs (power laws): the same criteria on the virtual rows the split cuts.
-        Only for graphs that were validated at build (the split needs one host readback)."""
+        """Long-row graphs (power laws): virtual rows for the heavy rows, the light rows through the second stage.
+        Only for graphs that were validated at build (the split needs host readbacks).  Rule refitted in round 4
+        (tools/kernel_choice_sweep.py, Zipf(1.1) degrees, 6.4 M edges: planned / split time 1.15-2.7 on every table up
+        to 275 MB at EVERY average degree from 16 — the light-row second stage made the split form independent of the
+        degree —, 1.0-1.04 at 410-550 MB, 0.7-0.9 from 800 MB unless the average degree is in the hundreds)."""
         if FORCE_KERNEL is not None or regular is not False or not self._S.validated:
             return False
         table = n_cols * F * 4
         n_virtual_bound = n_rows + self.nnz // SPLIT_ROW_EDGES
         if F % 4 != 0 or n_virtual_bound * SlicedCSR.N_SLICES >= 2 ** 31 - 1 or table < SPLIT_MIN_TABLE_BYTES:
             return False
-        return table <= _table_cap(SPLIT_TIERS, self.nnz / max(n_virtual_bound, 1))
+        degree = self.nnz / max(n_rows, 1)
+        if degree < SPLIT_MIN_DEGREE:
+            return False
+        return table <= (SPLIT_MAX_TABLE_BYTES_DENSE if degree >= SPLIT_DENSE_DEGREE else SPLIT_MAX_TABLE_BYTES)
 
     @staticmethod
     def _plan_if_needed(plan, max_deg):
