@@ -306,6 +306,7 @@ COMPACT_DROPPED = os.environ.get("DGMI_COMPACT_DROPPED", "1") != "0"
 MULT_FORM = os.environ.get("DGMI_MULT_FORM", "1") != "0"
 MULT_REL_TOL = 2.4e-7
 MULT_SHIFT, MULT_MAX_IDS = 28, 1 << 28
+COLUMN_PASS_MIN_ROWS, LONG_ROW_MIN_DEGREE = 32768, 384                # the launcher's column-pass rule (dgmi_sliced.hip); see _few_long_rows
 SPLIT_MIN_DEGREE, SPLIT_DENSE_DEGREE = 8, 300                       # average degree (edges / rows) of the whole graph
 SPLIT_MAX_TABLE_BYTES, SPLIT_MAX_TABLE_BYTES_DENSE = 350_000_000, 900_000_000
 
@@ -727,6 +728,17 @@ class CSRGraph:
             return False
         return table <= (SPLIT_MAX_TABLE_BYTES_DENSE if degree >= SPLIT_DENSE_DEGREE else SPLIT_MAX_TABLE_BYTES)
 
+    def _few_long_rows(self, F: int, n_rows: int, n_cols: int) -> bool:
+        """A REGULAR graph of few, long rows whose XCD slices of the table exceed an L2 (a config-5 edge-scaled shard:
+        6 250 rows of 1 600 edges over 100 000 sources): below 32 768 rows the launcher keeps one full-width pass (half-
+        width groups would leave too few waves), so the slice spills — cut into 256-edge virtual rows there are enough rows
+        for the column passes again (tools/long_rows_probe.py: 0.371 -> 0.322 ms, 0.345 -> 0.302, 0.339 -> 0.308; no gain
+        where a slice already fits: 0.247 -> 0.254)."""
+        if FORCE_KERNEL is not None or not self._S.validated or n_rows >= COLUMN_PASS_MIN_ROWS:
+            return False
+        slice_bytes = (n_cols + SlicedCSR.N_SLICES - 1) // SlicedCSR.N_SLICES * F * 4
+        return self.nnz >= LONG_ROW_MIN_DEGREE * max(n_rows, 1) and slice_bytes > (4 << 20)
+
     @staticmethod
     def _plan_if_needed(plan, max_deg):
         """A plan only cuts rows longer than its chunk; when a readback has told that none is (every kNN-4 graph, every
@@ -766,7 +778,9 @@ class CSRGraph:
         S = self._S
         if S.regular is None:
             self._decide_regular(X, False)
-        if X.dim() == 2 and self._use_sliced(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
+        long_rows = X.dim() == 2 and bool(S.regular) and self._few_long_rows(X.shape[1], S.n_dst, S.n_src)
+        if (X.dim() == 2 and not long_rows and self._use_sliced(X.shape[1], S.n_dst, S.n_src, S.regular)
+                and _sliced_ok(X, out)):
             if S.sliced is None:
                 S.sliced = SlicedCSR.from_csr(S.indptr, S.indices, S.eid, S.n_dst, S.n_src)  # one partition pass, no sort
             mult = self._mult_ids("sliced", S.sliced)
@@ -782,7 +796,8 @@ class CSRGraph:
                 return S.sliced.spmm(X, src_scale, dst_scale, out, vals=None, keep=self._keep, epi=epi, indices=mult[2], id_mult=True)
             return S.sliced.spmm(X, src_scale, dst_scale, out, vals=self._vals_for("sliced", S.sliced.eid), keep=self._keep,
                                  epi=epi)
-        if X.dim() == 2 and self._use_split(X.shape[1], S.n_dst, S.n_src, S.regular) and _sliced_ok(X, out):
+        if X.dim() == 2 and _sliced_ok(X, out) and (self._use_split(X.shape[1], S.n_dst, S.n_src, S.regular) or (
+                long_rows and self._use_sliced(X.shape[1], S.n_dst, S.n_src, S.regular))):
             if S.split is None:
                 S.split = _SplitSliced(S.indptr, S.eid, S.src, S.n_dst, S.n_src)
             c = self._compacted("split", S.split.sliced)
@@ -798,7 +813,9 @@ class CSRGraph:
         indptr_t, indices_t, eid_t, plan_t = self._t_struct()
         if S.regular_t is None:  # one-time readback of the reversed graph's maximum degree, when it can matter
             self._decide_regular(dY, True)
-        if dY.dim() == 2 and self._use_sliced(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):
+        long_rows = dY.dim() == 2 and bool(S.regular_t) and self._few_long_rows(dY.shape[1], S.n_src, S.n_dst)
+        if (dY.dim() == 2 and not long_rows and self._use_sliced(dY.shape[1], S.n_src, S.n_dst, S.regular_t)
+                and _sliced_ok(dY, out)):
             if S.sliced_t is None:
                 S.sliced_t = SlicedCSR.from_csr(indptr_t, indices_t, eid_t, S.n_src, S.n_dst)
             mult = self._mult_ids("sliced_t", S.sliced_t)
@@ -814,7 +831,8 @@ class CSRGraph:
                 return S.sliced_t.spmm(dY, dst_scale, src_scale, out, vals=None, keep=self._keep, indices=mult[2], id_mult=True)
             return S.sliced_t.spmm(dY, dst_scale, src_scale, out, vals=self._vals_for("sliced_t", S.sliced_t.eid),
                                    keep=self._keep)
-        if dY.dim() == 2 and self._use_split(dY.shape[1], S.n_src, S.n_dst, S.regular_t) and _sliced_ok(dY, out):
+        if dY.dim() == 2 and _sliced_ok(dY, out) and (self._use_split(dY.shape[1], S.n_src, S.n_dst, S.regular_t) or (
+                long_rows and self._use_sliced(dY.shape[1], S.n_src, S.n_dst, S.regular_t))):
             if S.split_t is None:
                 S.split_t = _SplitSliced(indptr_t, eid_t, S.dst, S.n_src, S.n_dst)
             c = self._compacted("split_t", S.split_t.sliced)

@@ -437,6 +437,18 @@ def test_csrgraph_picks_sliced_only_when_profitable(dev):
     assert torch.equal(gu.spmm_t(W), dx) and gu.regular_t is True and gu._sliced_t is not None
     su = ops.CSRGraph(skew._S.dst, skew._S.src, n_dst, n_src, check_range=False)
     assert torch.equal(su.spmm(X), ys_plain) and su.regular is False and su._sliced is None and su._S.split is None  # planned
+    # (r4) a regular graph of FEW, LONG rows over a table whose slices exceed an L2 (a config-5 edge-scaled shard): virtual
+    # rows, so that the launcher's column passes apply — same product
+    nl, ns_l, El = 3000, 70_000, 3_000_000  # degree 1000, slices of 8750 rows x 512 B = 4.5 MB
+    dl = torch.randint(0, nl, (El,), generator=gen, device=dev, dtype=torch.int32)
+    sl_ = torch.randint(0, ns_l, (El,), generator=gen, device=dev, dtype=torch.int32)
+    gl = ops.CSRGraph(dl, sl_, nl, ns_l)
+    Xl = torch.randn(ns_l, 128, device=dev)
+    yl = gl.spmm(Xl)
+    assert gl.regular and gl._few_long_rows(128, nl, ns_l) and gl._sliced is None and gl._S.split is not None and not gl._S.split.has_light
+    yl_plain = ops.spmm_csr_raw(gl.indptr, gl.indices, None, Xl, plan=gl.plan)
+    assert float((yl - yl_plain).abs().max()) <= 1e-5 * float(yl_plain.abs().max())
+    assert not gl._few_long_rows(64, nl, ns_l)  # 2.2 MB slices fit an L2: the plain sliced form
     # the decoder's edge-id CSRs never take it: every gathered row is used exactly once
     pairs = ops.EdgePairs(src[:600_000], dst[:600_000], n_src, n_dst)
     pairs.by_src().spmm(torch.randn(600_000, 128, device=dev))
