@@ -95,12 +95,18 @@ struct ScreenArgs {
   int cap_r, cap_c;       // slots of one row-direction region / of the column-direction region of a query's buffer
   float* part_val;     // SAMPLE: [N][subsets][4] the four largest approx scores of each subset (kUnset: none)
   const float* tau0;   // EMIT: [N] lower bound of the k-th largest approx score
+  const float* thr;    // EMIT: [Np] emission thresholds tau0 - 2 eps (4 for the padding rows: never reached)
   // EMIT: a query's buffer = kSplits regions of cap_r slots, one per candidate split (filled by the one workgroup
   // that owns (query tile, split): LDS counters, count written at the end) + one region of cap_c slots for the
   // scores other workgroups offer it in the triangular sweep (a global counter, zeroed before the launch)
   int32_t* cnt;        // [N][kSplits + 1] entries offered (may exceed the region: overflow)
   int2* buf;           // [N][kSplits * cap_r + cap_c] (candidate id, approx bits)
   int sym;             // EMIT: 1 = triangular sweep (tile pairs j >= i, scores offered in both directions)
+  // EMIT, 256 x 256 shape (knn_screen8_kernel): every kept pair is a 16-B record (query, candidate, approx bits, region) in a
+  // pool of 256-record chunks that the waves draw from one cursor; knn_pool_scatter_kernel files them into the queries' buffers
+  int4* pool;          // [pool_chunks][256]
+  int32_t* pool_ctl;   // [0]: chunks handed out; [1 + c]: records in chunk c
+  int pool_chunks;
 };
 
 template <bool EMIT, bool BIG>
@@ -358,6 +364,559 @@ __global__ __launch_bounds__(Shape<BIG>::kThreads, 2) void knn_screen_kernel(Scr
 #undef DGMI_SCREEN_GLOAD
 #undef DGMI_SCREEN_LSTORE
 
+// ---------------------------------------------------------------------------------------------------------------
+// (r4) The 256 x 256 shape, rebuilt around LDS-DMA staging and a phase-interleaved schedule (`knn_screen8_kernel`).
+//
+// The first 256 x 256 kernel (above, BIG = true) staged through registers with ONE barrier per 64-deep K chunk: all 8 waves
+// read fragments, multiplied, wrote the next chunk (8 `ds_write_b128` per lane = 830 LDS cycles per chunk at the 79 B/clk
+// store rate, nothing else running) and met at the barrier together — MFMA pipe busy 35-38 % (profiles/r02_knn_pmc.csv).
+// This one:
+//   * stages with `global_load_lds_dwordx4` (no VGPRs, no store pass): the LDS image of a wave-instruction is lane-linear
+//     (8 rows x 128 B), so the XOR swizzle sits on the per-lane SOURCE piece and on the fragment reads;
+//   * cuts a K chunk into 4 UNITS of 16 KB — U0 / U2 = the candidate rows each wave needs for its first / second
+//     32-candidate sub-tile, U1 / U3 = the query rows for its first / second 64-query sub-tile — and a chunk's work into 4
+//     PHASES, one 64 x 32 quadrant of the wave's 128 x 64 tile each (16 `v_mfma_f32_16x16x32_bf16`): phase 1 reads U1 (8
+//     `ds_read_b128`), phase 2 U2 (4), phase 3 U3 (8), phase 4 the NEXT chunk's U0 (4) into the registers phase 3 has freed;
+//   * every phase = [fragment reads, 2 LDS-DMA instructions of a later unit, `s_waitcnt vmcnt(8)`] barrier [16 MFMAs] barrier
+//     (at a tile's end: [DMA, the thresholding of the quadrant finished one phase ago, reads]).  Waves 4-7 run ONE barrier behind waves 0-3, so on every SIMD one
+//     wave multiplies while its partner loads (MI355X_MICROARCH 'Two waves per SIMD');
+//   * the DMA of unit g = 4 chunk + u is issued in phase g - 5 and waited for (counted, never 0: four units stay in flight
+//     across every barrier) at the end of the phase before its first read; a slot is refilled no earlier than two phases
+//     after its last read (the staggered waves' reads retire one barrier later).  The stream of units runs across tile
+//     boundaries; past the end it re-reads the last chunk, so the count never changes, and it is drained before exit.
+// A = candidates, B = queries as before: a lane's 4 results per MFMA belong to ONE query (its column), 4 candidate rows.
+constexpr int kUnitBytes = 16384;            // 128 rows x 128 B
+constexpr int kBufBytes = 4 * kUnitBytes;    // one K chunk of both tiles
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define DGMI_GLDS16(src_, dst_)                                                                              \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_),                    \
+                                   (__attribute__((address_space(3))) void*)(dst_), 16, 0, 0)
+// a raw barrier the compiler may move neither LDS accesses nor MFMAs across
+#define DGMI_PHASE_BARRIER()          \
+  {                                   \
+    asm volatile("" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0); \
+    __builtin_amdgcn_s_barrier();     \
+    __builtin_amdgcn_sched_barrier(0); \
+    asm volatile("" ::: "memory");    \
+  }
+
+// LDS accesses of the bookkeeping arrays (thresholds, group lists) are asm: hipcc puts `s_waitcnt vmcnt(0)` in front of every
+// LDS access it can see while an LDS-DMA is in flight (it cannot tell the staging buffers from these arrays), which drained the
+// four units in flight at every threshold read and every append.  "memory" keeps the compiler's own accesses in order; the
+// hidden operations only make its counted `lgkmcnt` waits more conservative (LDS operations of a wave complete in order).
+typedef int intx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ floatx4 lds_read_f4(uint32_t addr) {
+  floatx4 r;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(addr) : "memory");
+  return r;
+}
+
+// What the EMIT pass keeps: per pair 1 in ~1400 (k = 4, N = 100 000: tau' comes from an eighth of the candidates), i.e. ~3 per
+// wave and finished quadrant — not rare, so the appends are built for throughput, and so that the main loop sees NO vector-memory
+// operation besides its LDS-DMA (the counted `vmcnt(8)` is in order: a store issued in an epilogue would have to complete within
+// four phases, and a returning atomic drains the queue).  A lane whose 8 scores of one (query, quadrant) hold a candidate for
+// either direction writes them as a GROUP (48 B: 8-B header + the two accumulator registers as they stand) into its WAVE's list in
+// LDS: position by ballot rank, cursor in a scalar register, no atomic, no wait.  Once per tile the wave files its list: one
+// lane per (group, score), exact comparison, survivors ranked by ballot into 16-B records of the wave's current pool chunk
+// (global, 256 records, drawn from one cursor with a returning atomic every ~20 tiles) — two or three coalesced stores per
+// tile and wave.  Slot allocation in the queries' buffers is knn_pool_scatter_kernel's.
+constexpr int kGrpCap = 64;     // groups per wave list (one epilogue position can add 64)
+constexpr int kGrpBytes = 48;   // header (8 of 16 B) + 8 scores
+constexpr int kChunk = 256;     // records per pool chunk
+constexpr int kOverflowMark = 0x40000000;  // an entry count no region holds: the query is recomputed exactly
+
+struct Screen8Lane {
+  int wq, wc, fr, kg, lane;
+  int q_tile, split, N, cap_r, cap_c;
+  int64_t q_slots;
+  uint32_t list;     // LDS byte address of this wave's group list
+  uint32_t ethr_c;   // LDS byte address of the candidate rows' thresholds [2][256]
+  uint32_t ethr_q;   // LDS byte address of the workgroup's own queries' thresholds [wq][fr][nt]: a lane's 8 are 32 B
+};
+struct Screen8Wave {  // wave-uniform
+  int g_cnt;          // groups in the list
+  int chunk, used;    // current pool chunk (-1: none / pool exhausted) and records in it
+};
+
+// the wave's list -> pool records
+__device__ __forceinline__ void screen8_flush(const ScreenArgs& a, const Screen8Lane& L, Screen8Wave& W) {
+  const int total = W.g_cnt * 8;
+  for (int base = 0; base < total; base += 64) {
+    const int idx = base + L.lane, j = idx & 7;
+    const bool valid = idx < total;
+    const uint32_t g_at = L.list + (uint32_t)((valid ? idx : 0) >> 3) * kGrpBytes;
+    int hq, hc;  // header: (direction << 31 | threshold parity << 30 | query), candidate of (mt = 0, j = 0)
+    float s;
+    asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:4\n\tds_read_b32 %2, %4 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(hq), "=&v"(hc), "=&v"(s)
+                 : "v"(g_at), "v"(g_at + 4u * (uint32_t)j)
+                 : "memory");
+    const bool dir2 = hq < 0;
+    const int qid = hq & 0x3fffffff, cand = hc + 16 * (j >> 2) + (j & 3);
+    float thr;
+    {
+      // direction 2: the threshold of the candidate row (tile-local row = candidate & 255); direction 1: the query's own
+      const int ql = qid & 255;
+      const uint32_t t_at = dir2 ? L.ethr_c + (((uint32_t)hq >> 30) & 1u) * 1024u + 4u * (uint32_t)(cand & 255)
+                                 : L.ethr_q + 4u * (uint32_t)((((ql >> 7) * 16 + (ql & 15)) << 3) + ((ql >> 4) & 7));
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(thr) : "v"(t_at) : "memory");
+    }
+    const bool hit = valid && s >= thr;  // (padding candidates carry kMasked scores, padding rows a threshold of 4)
+    const uint64_t bal = __ballot(hit);
+    if (bal != 0) {
+      const int n_hit = __popcll(bal);
+      if (W.chunk < 0 || W.used + n_hit > kChunk) {  // a new chunk (the rest of the old one stays empty)
+        int c = -1;
+        if (L.lane == 0) {
+          if (W.chunk >= 0) a.pool_ctl[1 + W.chunk] = W.used;
+          c = atomicAdd(&a.pool_ctl[0], 1);
+        }
+        c = __builtin_amdgcn_readfirstlane(c);
+        W.chunk = c < a.pool_chunks ? c : -1;
+        W.used = 0;
+      }
+      if (hit) {
+        const int query = dir2 ? cand : qid, other = dir2 ? qid : cand, region = dir2 ? kSplits : L.split;
+        if (W.chunk >= 0) {
+          const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+          a.pool[(int64_t)W.chunk * kChunk + W.used + rank] = make_int4(query, other, __float_as_int(s), region);
+        } else {  // pool exhausted: straight into the query's region
+          const uint32_t slot = (uint32_t)atomicAdd(&a.cnt[(int64_t)query * (kSplits + 1) + region], 1);
+          if (slot < (uint32_t)(dir2 ? L.cap_c : L.cap_r))
+            a.buf[(int64_t)query * L.q_slots + (int64_t)region * L.cap_r + slot] = make_int2(other, __float_as_int(s));
+        }
+      }
+      if (W.chunk >= 0) W.used += n_hit;
+    }
+  }
+  W.g_cnt = 0;
+}
+
+// thresholding of one finished 64-query x 32-candidate quadrant (QQ, CQ) of tile `tl`, then the quadrant is cleared
+template <bool EMIT, int QQ, int CQ>
+__device__ __forceinline__ void screen8_quadrant(floatx4 (&acc)[8][4], float (&top)[8][4], const Screen8Lane& L, Screen8Wave& W,
+                                                 uint32_t& ovf, const ScreenArgs& a, int tl, int par) {
+  const int c0 = tl * 256 + L.wc * 64 + CQ * 32 + 4 * L.kg;  // candidate of (mt = 0, j = 0); (mt, j): + 16 mt + j
+  if (c0 - 4 * L.kg + 32 > a.N) {                            // padding candidates (last tile only)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c0 + 16 * m + j >= a.N) acc[4 * QQ + n][2 * CQ + m][j] = kMasked;
+  }
+#define DGMI_S8_MAX8(n_) fmaxf(fmaxf(fmaxf(acc[4 * QQ + (n_)][2 * CQ][0], acc[4 * QQ + (n_)][2 * CQ][1]), fmaxf(acc[4 * QQ + (n_)][2 * CQ][2], acc[4 * QQ + (n_)][2 * CQ][3])), \
+                               fmaxf(fmaxf(acc[4 * QQ + (n_)][2 * CQ + 1][0], acc[4 * QQ + (n_)][2 * CQ + 1][1]), fmaxf(acc[4 * QQ + (n_)][2 * CQ + 1][2], acc[4 * QQ + (n_)][2 * CQ + 1][3])))
+  if (EMIT) {
+    // direction 1: the lane's own queries (thresholds in registers; 4 for a padding query: never).  Direction 2 (triangular
+    // sweep, off the diagonal): the same scores offered to the queries that are this tile's candidate rows — pre-filter: the
+    // lowest of the lane's 8 row thresholds.  One group serves both.
+    float tmin = 4.0f;
+    if (a.sym && tl != L.q_tile) {
+      const uint32_t t_at = L.ethr_c + (uint32_t)par * 1024u + 4u * (uint32_t)(L.wc * 64 + CQ * 32 + 4 * L.kg);
+      const floatx4 t0 = lds_read_f4(t_at);
+      tmin = fminf(fminf(t0[0], t0[1]), fminf(t0[2], t0[3]));
+      const floatx4 t1 = lds_read_f4(t_at + 64u);
+      tmin = fminf(tmin, fminf(fminf(t1[0], t1[1]), fminf(t1[2], t1[3])));
+    }
+    const floatx4 ethr = lds_read_f4(L.ethr_q + 4u * (uint32_t)(((L.wq * 16 + L.fr) << 3) + 4 * QQ));  // (4 for a padding query)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int nt = 4 * QQ + n;
+      const float mxn = DGMI_S8_MAX8(n);
+      const bool d1 = mxn >= ethr[n], d2 = mxn >= tmin && ethr[n] < 3.5f;  // (not for a padding query)
+      const uint64_t b1 = __ballot(d1), b2 = __ballot(d2);
+      if ((b1 | b2) != 0) {
+        int qt = L.q_tile;
+        asm volatile("" : "+s"(qt));  // (computed here, not kept in a register across the loop)
+        const int qg = qt * 256 + L.wq * 128 + nt * 16 + L.fr;
+        // a lane may write two groups (one per direction): direction-1 groups first
+        const int n1 = __popcll(b1), n2 = __popcll(b2);
+        if (W.g_cnt + n1 + n2 > kGrpCap) screen8_flush(a, L, W);  // (a diagonal tile's self-matches alone are 64 groups)
+        const int r1 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+        const int r2 = n1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2, 0u));
+        if (d1) {
+          const int g = W.g_cnt + r1;
+          if (g < kGrpCap) {
+            const uint32_t at = L.list + (uint32_t)g * kGrpBytes;
+            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4\n\tds_write_b128 %0, %3 offset:16\n\tds_write_b128 %0, %4 offset:32" ::"v"(at),
+                         "v"(qg), "v"(c0), "v"(acc[nt][2 * CQ]), "v"(acc[nt][2 * CQ + 1])
+                         : "memory");
+          } else {
+            ovf |= 1u << nt;
+          }
+        }
+        if (d2) {
+          const int g = W.g_cnt + r2;
+          if (g < kGrpCap) {
+            const uint32_t at = L.list + (uint32_t)g * kGrpBytes;
+            const int hq = (int)(0x80000000u | ((uint32_t)par << 30) | (uint32_t)qg);
+            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4\n\tds_write_b128 %0, %3 offset:16\n\tds_write_b128 %0, %4 offset:32" ::"v"(at),
+                         "v"(hq), "v"(c0), "v"(acc[nt][2 * CQ]), "v"(acc[nt][2 * CQ + 1])
+                         : "memory");
+          } else {  // no room: the 8 rows' queries are recomputed exactly
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if (c0 + 16 * m + j < a.N) a.cnt[(int64_t)(c0 + 16 * m + j) * (kSplits + 1) + kSplits] = kOverflowMark;
+          }
+        }
+        const int g_new = W.g_cnt + n1 + n2;
+        W.g_cnt = g_new < kGrpCap ? g_new : kGrpCap;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int nt = 4 * QQ + n;
+      if (DGMI_S8_MAX8(n) > top[nt][3]) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float s = acc[nt][2 * CQ + m][j];
+            top[nt][3] = fmaxf(top[nt][3], fminf(top[nt][2], s));  // branch-free sorted insert, lowest first
+            top[nt][2] = fmaxf(top[nt][2], fminf(top[nt][1], s));
+            top[nt][1] = fmaxf(top[nt][1], fminf(top[nt][0], s));
+            top[nt][0] = fmaxf(top[nt][0], s);
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[4 * QQ + n][2 * CQ + m][j] = 0.f;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(512, 2) void knn_screen8_kernel(ScreenArgs a) {
+#define S8_BAR() DGMI_PHASE_BARRIER()
+#define S8_VMW() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+  extern __shared__ __align__(16) unsigned char screen_lds[];
+  unsigned char* const smem = screen_lds;                                   // [2 buffers][4 units][128 rows][128 B]
+  float* ethr_c = reinterpret_cast<float*>(smem + 2 * kBufBytes);           // EMIT, triangular: [2][256] thresholds of candidate rows
+  float* ethr_q = ethr_c + 512;                                             // EMIT: [2][16][8] thresholds of the workgroup's queries
+  unsigned char* lists = smem + 2 * kBufBytes + 3072;                       // EMIT: [8 waves][kGrpCap][kGrpBytes]
+
+  constexpr int kT = 256;
+  const int n_tiles = a.Np / kT;
+  const int b = (int)blockIdx.x, xcd = b & 7, jb = b >> 3;
+  const int inner = jb & 63, G = (jb >> 6) * 8 + xcd;
+  const int q_tile = G * 8 + (inner & 7), split = inner >> 3;
+  if (q_tile >= n_tiles) return;
+  int t0, tstep, nt;
+  if (EMIT) {
+    const int first = a.sym ? q_tile : 0;
+    const int per = (n_tiles - first + kSplits - 1) / kSplits;
+    t0 = first + split * per;
+    tstep = 1;
+    nt = t0 + per <= n_tiles ? per : (n_tiles > t0 ? n_tiles - t0 : 0);
+  } else {
+    const int stride = n_tiles >= 64 ? 8 : (n_tiles >= 8 ? n_tiles / 8 : 1);
+    t0 = stride * split;
+    tstep = stride * kSplits;
+    nt = n_tiles > t0 ? (n_tiles - t0 + tstep - 1) / tstep : 0;
+  }
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Screen8Lane L;
+  L.wq = wave & 1, L.wc = wave >> 1, L.fr = lane & 15, L.kg = lane >> 4;
+  L.q_tile = q_tile, L.split = split, L.N = a.N, L.cap_r = a.cap_r, L.cap_c = a.cap_c;
+  L.q_slots = (int64_t)kSplits * a.cap_r + a.cap_c;
+  L.lane = lane;
+  L.list = lds_addr(lists) + (uint32_t)wave * (kGrpCap * kGrpBytes);
+  L.ethr_c = lds_addr(ethr_c), L.ethr_q = lds_addr(ethr_q);
+  Screen8Wave W;
+  W.g_cnt = 0, W.chunk = -1, W.used = 0;
+  uint32_t ovf = 0;  // EMIT: bit nt = a direction-1 group of query sub-tile nt found the list full
+  const int Dp = a.Dp, nK = Dp / kSK;
+  const int total = nt * nK;
+
+  float top[8][4];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) top[n][0] = top[n][1] = top[n][2] = top[n][3] = kUnset;
+  if (EMIT) {
+    if (tid < kT) ethr_q[(((tid >> 7) * 16 + (tid & 15)) << 3) + ((tid >> 4) & 7)] = a.thr[q_tile * kT + tid];
+    if (a.sym && nt > 0 && tid < kT) ethr_c[tid] = a.thr[t0 * kT + tid];
+  }
+  floatx4 acc[8][4];
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[n][m] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  // staging: wave-instruction i of a unit fills image rows (8 i + wave) 8 .. + 8; lane -> row + (lane >> 3), slot lane & 7,
+  // which holds source piece (lane & 7) ^ swizzle(image row), swizzle(r) = (r >> 1) & 7.  Source address = a running
+  // scalar pointer (chunk, unit) + one of four per-lane 32-bit offsets (queries / candidates, instruction 0 / 1).
+  const int64_t rowB = (int64_t)Dp * 2;
+  const int piece = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
+  const uint32_t voQ0 = (uint32_t)((wave * 8 + (lane >> 3)) * (int)rowB + piece * 16);
+  const uint32_t voC0 = (uint32_t)(((wave >> 2) * 64 + (wave & 3) * 8 + (lane >> 3)) * (int)rowB + piece * 16);
+  const int64_t half_rows = 128 * rowB;  // instruction 1 of a unit: 128 rows further on
+  const unsigned char* const xb = reinterpret_cast<const unsigned char*>(a.Xb);
+  const int64_t q_sub1 = 64 * rowB, c_sub1 = 32 * rowB;
+  unsigned char* const st_dst = smem + wave * 1024;
+  // instruction I (0 / 1) of unit U of the chunk at byte offsets (oq_, oc_) into buffer buf_
+#define DGMI_S8_ISSUE1(U, I, oq_, oc_, buf_)                                                                     \
+  {                                                                                                              \
+    int64_t o_ = ((U)&1) ? (oq_) + ((U) == 3 ? q_sub1 : 0) : (oc_) + ((U) == 2 ? c_sub1 : 0);                     \
+    const unsigned char* sb_ = xb + o_ + ((I) ? half_rows : 0);                                                  \
+    asm volatile("" : "+s"(sb_));                                                                                \
+    uint32_t vo_ = ((U)&1) ? voQ0 : voC0;                                                                        \
+    asm volatile("" : "+v"(vo_));                                                                                \
+    DGMI_GLDS16(sb_ + vo_, st_dst + (buf_) * kBufBytes + (U) * kUnitBytes + (I) * 8192);                          \
+  }
+#define DGMI_S8_ISSUE(U, oq_, oc_, buf_) \
+  {                                      \
+    DGMI_S8_ISSUE1(U, 0, oq_, oc_, buf_) \
+    DGMI_S8_ISSUE1(U, 1, oq_, oc_, buf_) \
+  }
+  // fragment reads: image row (sub-tile base + 16 t + fr), slot (4 kk + kg) ^ swizzle(fr)
+  const int swzr = (L.fr >> 1) & 7;
+  const int q_rd0 = kUnitBytes + (L.wq * 64 + L.fr) * 128, c_rd0 = (L.wc * 32 + L.fr) * 128;
+  const int sl0 = ((0 + L.kg) ^ swzr) << 4, sl1 = ((4 + L.kg) ^ swzr) << 4;
+#define DGMI_S8_FRAG(off_) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + (off_)))
+#define DGMI_S8_RD(dst_, off_) dst_ = DGMI_S8_FRAG(off_)
+  // 16 MFMAs of one quadrant; with the LDS-DMA of this phase's unit between them when it is issued from the MFMA part
+#define DGMI_S8_MMA(QB, CB, cf_)                                                                                             \
+  {                                                                                                                          \
+    __builtin_amdgcn_s_setprio(1);                                                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int n = 0; n < 4; ++n)                           \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[QB + n][CB + m] =                                                  \
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf_[m][kk], qf[n][kk], acc[QB + n][CB + m], 0, 0, 0);                    \
+    __builtin_amdgcn_s_setprio(0);                                                                                           \
+  }
+
+  if (total > 0) {  // (workgroup-uniform)
+  // chunk cursors: (tile, kc) = the chunk being multiplied; byte offsets of the next chunk's rows (o1q, o1c) and of the one
+  // after (o2q, o2c), clamped at the last chunk
+  int tile = t0, kc = 0, ci = 0;
+  const int64_t oq0 = (int64_t)q_tile * kT * rowB, oc0 = (int64_t)t0 * kT * rowB;
+  const int64_t tile_step = (int64_t)tstep * kT * rowB - (int64_t)(nK - 1) * 128;
+  int k1 = 0, k2;
+  int64_t o1q = oq0, o1c = oc0, o2q, o2c;
+#define DGMI_S8_ADVANCE(ki_, oqi_, oci_, ko_, oqo_, oco_, idx_) \
+  {                                                             \
+    ko_ = ki_, oqo_ = oqi_, oco_ = oci_;                        \
+    if ((idx_) + 1 < total) {                                   \
+      if (ki_ + 1 == nK)                                        \
+        ko_ = 0, oqo_ = oqi_ - (int64_t)(nK - 1) * 128, oco_ = oci_ + tile_step; \
+      else                                                      \
+        ko_ = ki_ + 1, oqo_ = oqi_ + 128, oco_ = oci_ + 128;    \
+    }                                                           \
+  }
+  // prologue: units 0..5 (chunk 0 whole, chunk 1's U0, U1)
+  DGMI_S8_ISSUE(0, oq0, oc0, 0);
+  DGMI_S8_ISSUE(1, oq0, oc0, 0);
+  DGMI_S8_ISSUE(2, oq0, oc0, 0);
+  DGMI_S8_ISSUE(3, oq0, oc0, 0);
+  DGMI_S8_ADVANCE(k1, o1q, o1c, k1, o1q, o1c, 0);
+  DGMI_S8_ADVANCE(k1, o1q, o1c, k2, o2q, o2c, 1);
+  DGMI_S8_ISSUE(0, o1q, o1c, 1);
+  DGMI_S8_ISSUE(1, o1q, o1c, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  S8_BAR();
+  if (wave >= 4) S8_BAR();  // waves 4-7 run one barrier behind
+
+  bf16x8 qf[4][2], cf0[2][2], cf1[2][2];
+  int tcount = 0;           // tiles finished by this workgroup
+  int prev_tile = tile;     // the tile whose last quadrant is still to be thresholded
+  // chunk 0's first candidate sub-tile (every later one is read in phase 4 of the chunk before)
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    DGMI_S8_RD(cf1[m][0], c_rd0 + m * 2048 + sl0);
+    DGMI_S8_RD(cf1[m][1], c_rd0 + m * 2048 + sl1);
+  }
+  for (; ci < total; ++ci) {
+    const int bo = (ci & 1) * kBufBytes;
+    const bool first = kc == 0, last = kc == nK - 1;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) cf0[m][0] = cf1[m][0], cf0[m][1] = cf1[m][1];
+    // A load part is [fragment reads, this phase's LDS-DMA] — the reads first: their latency passes while the DMA is issued.
+    // Where a quadrant was finished one phase ago (a tile's last chunk and the phase after it) the order is [DMA, thresholding
+    // of that quadrant, reads]: the fragment registers are dead until the reads, and the epilogue with the list filing inside it
+    // needs them (a spilled register costs a scratch reload, a vector-memory operation whose wait drains the DMA queue).
+#define S8_FENCE() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define S8_READS_1()                                                 \
+  {                                                                  \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) {                  \
+      DGMI_S8_RD(qf[n][0], bo + q_rd0 + n * 2048 + sl0);             \
+      DGMI_S8_RD(qf[n][1], bo + q_rd0 + n * 2048 + sl1);             \
+    }                                                                \
+  }
+  /* the NEXT chunk's first candidate sub-tile, into the registers of the second (dead since phase 3's MFMAs) */ \
+
+#define S8_READS_4()                                                               \
+  {                                                                                \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                \
+      DGMI_S8_RD(cf1[m][0], (bo ^ kBufBytes) + c_rd0 + m * 2048 + sl0);            \
+      DGMI_S8_RD(cf1[m][1], (bo ^ kBufBytes) + c_rd0 + m * 2048 + sl1);            \
+    }                                                                              \
+  }
+#define S8_READS_2()                                                               \
+  {                                                                                \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                \
+      DGMI_S8_RD(cf1[m][0], bo + 2 * kUnitBytes + c_rd0 + m * 2048 + sl0);         \
+      DGMI_S8_RD(cf1[m][1], bo + 2 * kUnitBytes + c_rd0 + m * 2048 + sl1);         \
+    }                                                                              \
+  }
+#define S8_READS_3()                                                               \
+  {                                                                                \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                \
+      DGMI_S8_RD(qf[n][0], bo + 2 * kUnitBytes + q_rd0 + n * 2048 + sl0);          \
+      DGMI_S8_RD(qf[n][1], bo + 2 * kUnitBytes + q_rd0 + n * 2048 + sl1);          \
+    }                                                                              \
+  }
+    // ---- phase 1: quadrant (Q0, C0) ----
+    if (first && ci > 0) {
+      DGMI_S8_ISSUE(2, o1q, o1c, (ci + 1) & 1);
+      screen8_quadrant<EMIT, 1, 0>(acc, top, L, W, ovf, a, prev_tile, (tcount - 1) & 1);
+      if (EMIT && W.g_cnt > 0) screen8_flush(a, L, W);  // the finished tile's groups (its thresholds stay until this tile's phase 3)
+      S8_FENCE();
+      S8_READS_1();
+    } else {
+      S8_READS_1();
+      DGMI_S8_ISSUE(2, o1q, o1c, (ci + 1) & 1);
+    }
+    S8_VMW();
+    S8_BAR();
+    DGMI_S8_MMA(0, 0, cf0);
+    S8_BAR();
+    // ---- phase 2: quadrant (Q0, C1) ----
+    if (last) {
+      DGMI_S8_ISSUE(3, o1q, o1c, (ci + 1) & 1);
+      screen8_quadrant<EMIT, 0, 0>(acc, top, L, W, ovf, a, tile, tcount & 1);
+      S8_FENCE();
+      S8_READS_2();
+    } else {
+      S8_READS_2();
+      DGMI_S8_ISSUE(3, o1q, o1c, (ci + 1) & 1);
+    }
+    S8_VMW();
+    S8_BAR();
+    DGMI_S8_MMA(0, 2, cf1);
+    S8_BAR();
+    // ---- phase 3: quadrant (Q1, C1) ----
+    if (last) {
+      DGMI_S8_ISSUE(0, o2q, o2c, ci & 1);
+      screen8_quadrant<EMIT, 0, 1>(acc, top, L, W, ovf, a, tile, tcount & 1);
+      S8_FENCE();
+      S8_READS_3();
+    } else {
+      S8_READS_3();
+      DGMI_S8_ISSUE(0, o2q, o2c, ci & 1);
+    }
+    if (EMIT && first && a.sym && wave < 4 && ci + nK < total) {
+      // the NEXT tile's row thresholds, by LDS-DMA like everything else (4 B per lane, one instruction in each of waves 0-3:
+      // their extra entry in the queue only makes the counted waits stricter); read from the next tile's last chunk on
+      int ln_ = lane;
+      asm volatile("" : "+v"(ln_));  // (the address is made here, not carried through the loop)
+      const float* src_ = a.thr + (int64_t)(tile + tstep) * kT + wave * 64 + ln_;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,
+                                       (__attribute__((address_space(3))) void*)(ethr_c + ((tcount + 1) & 1) * 256 + wave * 64), 4, 0, 0);
+    }
+    S8_VMW();
+    S8_BAR();
+    DGMI_S8_MMA(4, 2, cf1);
+    S8_BAR();
+    // ---- phase 4: quadrant (Q1, C0) ----
+    if (last) {
+      DGMI_S8_ISSUE(1, o2q, o2c, ci & 1);
+      screen8_quadrant<EMIT, 1, 1>(acc, top, L, W, ovf, a, tile, tcount & 1);
+      S8_FENCE();
+      S8_READS_4();
+    } else {
+      S8_READS_4();
+      DGMI_S8_ISSUE(1, o2q, o2c, ci & 1);
+    }
+    S8_VMW();
+    S8_BAR();
+    DGMI_S8_MMA(4, 0, cf0);
+    S8_BAR();
+#undef S8_FENCE
+#undef S8_READS_1
+#undef S8_READS_2
+#undef S8_READS_3
+#undef S8_READS_4
+
+    if (last) prev_tile = tile, ++tcount;
+    if (ci + 1 < total) {
+      if (last) kc = 0, tile += tstep; else ++kc;
+    }
+    k1 = k2, o1q = o2q, o1c = o2c;
+    DGMI_S8_ADVANCE(k1, o1q, o1c, k2, o2q, o2c, ci + 2);
+  }
+  if (wave < 4) S8_BAR();  // waves 0-3 end one barrier ahead
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may be in flight when the workgroup's LDS is released
+  screen8_quadrant<EMIT, 1, 0>(acc, top, L, W, ovf, a, prev_tile, (tcount - 1) & 1);
+  if (EMIT && W.g_cnt > 0) screen8_flush(a, L, W);
+  }
+
+  if (EMIT) {
+    if (W.chunk >= 0 && lane == 0) a.pool_ctl[1 + W.chunk] = W.used;
+    if (ovf != 0) {
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        const int qg = q_tile * kT + L.wq * 128 + n * 16 + L.fr;
+        if (((ovf >> n) & 1u) && qg < a.N) a.cnt[(int64_t)qg * (kSplits + 1) + split] = kOverflowMark;
+      }
+    }
+  } else {
+    // a query's column is seen by the four lanes fr + 16 kg: lanes kg and kg ^ 1 merge their lists, so that the subsets
+    // (and the layout of part_val) are those of the first 256 x 256 kernel: (split, wc, kg >> 1), four scores each
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      float o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = __shfl_xor(top[n][i], 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float s = o[i];
+        top[n][3] = fmaxf(top[n][3], fminf(top[n][2], s));
+        top[n][2] = fmaxf(top[n][2], fminf(top[n][1], s));
+        top[n][1] = fmaxf(top[n][1], fminf(top[n][0], s));
+        top[n][0] = fmaxf(top[n][0], s);
+      }
+      const int qg = q_tile * kT + L.wq * 128 + n * 16 + L.fr;
+      if ((L.kg & 1) == 0 && qg < a.N)
+        *reinterpret_cast<float4*>(a.part_val + ((int64_t)qg * Shape<true>::kSubsets + (split * 4 + L.wc) * 2 + (L.kg >> 1)) * 4) =
+            make_float4(top[n][0], top[n][1], top[n][2], top[n][3]);
+    }
+  }
+}
+#undef S8_BAR
+#undef S8_VMW
+#undef DGMI_S8_ISSUE1
+#undef DGMI_S8_ISSUE
+#undef DGMI_S8_FRAG
+#undef DGMI_S8_RD
+#undef DGMI_S8_MMA
+#undef DGMI_S8_ADVANCE
+// the pool's records, filed into the buffers of the queries they belong to (region < kSplits: the candidate split's region
+// of cap_r slots; kSplits: the column region of cap_c slots); a count beyond the region flags the query for the exact path
+__global__ __launch_bounds__(256) void knn_pool_scatter_kernel(const int4* __restrict__ pool, const int32_t* __restrict__ pool_ctl,
+                                                               int cap_r, int cap_c, int32_t* __restrict__ cnt, int2* __restrict__ buf) {
+  const int chunk = (int)blockIdx.x, n = pool_ctl[1 + chunk];
+  if ((int)threadIdx.x >= n) return;
+  const int4 rec = pool[(int64_t)chunk * kChunk + threadIdx.x];
+  const int64_t q_slots = (int64_t)kSplits * cap_r + cap_c;
+  const uint32_t slot = (uint32_t)atomicAdd(&cnt[(int64_t)rec.x * (kSplits + 1) + rec.w], 1);
+  if (slot < (uint32_t)(rec.w < kSplits ? cap_r : cap_c)) buf[(int64_t)rec.x * q_slots + (int64_t)rec.w * cap_r + slot] = make_int2(rec.y, rec.z);
+}
+#undef DGMI_GLDS16
+#undef DGMI_PHASE_BARRIER
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -389,14 +948,18 @@ __device__ __forceinline__ float wave_kth_largest(float (&v)[J], int k, int lane
 
 // tau0[q] = k-th largest of the sample scores (top four of each subset: 128 or 256 values) of query q, one wave per query
 template <int J>
-__global__ __launch_bounds__(256) void knn_tau_kernel(const float* __restrict__ part_val, int N, int k, float* __restrict__ tau0) {
+__global__ __launch_bounds__(256) void knn_tau_kernel(const float* __restrict__ part_val, int N, int Np, int k, float* __restrict__ tau0,
+                                                      float* __restrict__ thr) {
   const int lane = threadIdx.x & 63, q = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= N) return;
+  if (q >= N) {
+    if (q < Np && lane == 0) thr[q] = 4.0f;  // a padding row offers and is offered nothing
+    return;
+  }
   float v[J];
 #pragma unroll
   for (int i = 0; i < J; ++i) v[i] = part_val[(int64_t)q * (64 * J) + lane + 64 * i];
   const float t = wave_kth_largest<J>(v, k, lane);
-  if (lane == 0) tau0[q] = t;
+  if (lane == 0) tau0[q] = t, thr[q] = t - 2.f * kScreenEps;
 }
 
 // k-th largest of the values v[0..J) held per lane across the wave, by bisection on the order-preserving integer
@@ -568,7 +1131,8 @@ bool screen_sym(int64_t N, int k) {
 struct ScreenLayout {
   bool big, sym;
   int Np, Dp, cap_r, cap_c;
-  size_t xb, part, tau, cnt, buf, flags, total;
+  int pool_chunks;  // 256-record chunks of the 256 x 256 EMIT kernel's pool (0: none)
+  size_t xb, part, tau, thr, cnt, buf, flags, pool, pool_ctl, total;
 };
 
 ScreenLayout screen_layout(int64_t N, int64_t D, int k) {
@@ -584,9 +1148,16 @@ ScreenLayout screen_layout(int64_t N, int64_t D, int k) {
   L.xb = at, at += align256((size_t)L.Np * L.Dp * 2);
   L.part = at, at += align256((size_t)N * Shape<true>::kSubsets * 4 * 4);
   L.tau = at, at += align256((size_t)N * 4);
+  L.thr = at, at += align256((size_t)L.Np * 4);
   L.cnt = at, at += align256((size_t)N * (kSplits + 1) * 4);
   L.buf = at, at += align256((size_t)N * (kSplits * L.cap_r + L.cap_c) * 8);
   L.flags = at, at += align256((size_t)N * 4);
+  // the phase-interleaved 256 x 256 kernel (k <= 16) keeps ~ 20 k pairs per query (tau' comes from an eighth of the
+  // candidates, both directions of the triangular sweep, the 2 eps margin): room for 32 k + 96 per query, in chunks (each
+  // wave of each workgroup holds one partly filled chunk: the 2048)
+  L.pool_chunks = L.big && k <= 16 ? (int)(((size_t)N * (32 * k + 96) + kChunk - 1) / kChunk) + 2048 : 0;
+  L.pool = at, at += align256((size_t)L.pool_chunks * kChunk * 16);
+  L.pool_ctl = at, at += align256(L.pool_chunks ? ((size_t)L.pool_chunks + 1) * 4 : 0);
   L.total = at;
   return L;
 }
@@ -596,19 +1167,40 @@ hipError_t launch_screen(const ScreenArgs& a, int64_t N, int k, hipStream_t s) {
   using S = Shape<BIG>;
   const int n_groups = (a.Np / S::kTile + 7) / 8;
   const unsigned blocks = (unsigned)(8 * ((n_groups + 7) / 8) * 64);
-  const size_t lds_sample = 2 * S::kStage, lds_emit = 2 * S::kStage + 2 * S::kTile * 4;
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<false, BIG>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sample);
+  // the 256 x 256 shape runs the phase-interleaved LDS-DMA kernel up to k = 16 (DGMI_KNN_SCREEN_V1=1: the first kernel, for
+  // A/B tools); beyond, a quadrant keeps too many pairs for its group lists and the first kernel stays
+  static const bool v1 = [] {
+    const char* e = getenv("DGMI_KNN_SCREEN_V1");
+    return e != nullptr && e[0] == '1';
+  }();
+  const bool v8 = BIG && a.pool != nullptr && !v1 && a.Dp >= 2 * kSK;  // (one-chunk rows: the threshold DMA would arrive late)
+  const size_t lds_sample = v8 ? 2 * kBufBytes : 2 * S::kStage;
+  const size_t lds_emit = v8 ? 2 * kBufBytes + 3072 + 8 * kGrpCap * kGrpBytes : 2 * S::kStage + 2 * S::kTile * 4;
+  const void* f_sample = v8 ? reinterpret_cast<const void*>(knn_screen8_kernel<false>)
+                            : reinterpret_cast<const void*>(knn_screen_kernel<false, BIG>);
+  const void* f_emit = v8 ? reinterpret_cast<const void*>(knn_screen8_kernel<true>)
+                          : reinterpret_cast<const void*>(knn_screen_kernel<true, BIG>);
+  hipError_t err = hipFuncSetAttribute(f_sample, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sample);
   if (err != hipSuccess) return err;
-  err = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<true, BIG>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_emit);
+  err = hipFuncSetAttribute(f_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_emit);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL((knn_screen_kernel<false, BIG>), dim3(blocks), dim3(S::kThreads), lds_sample, s, a);
-  hipLaunchKernelGGL((knn_tau_kernel<S::kSubsets * 4 / 64>), dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, a.part_val, (int)N, k,
-                     const_cast<float*>(a.tau0));
+  if (v8)
+    hipLaunchKernelGGL((knn_screen8_kernel<false>), dim3(blocks), dim3(512), lds_sample, s, a);
+  else
+    hipLaunchKernelGGL((knn_screen_kernel<false, BIG>), dim3(blocks), dim3(S::kThreads), lds_sample, s, a);
+  hipLaunchKernelGGL((knn_tau_kernel<S::kSubsets * 4 / 64>), dim3((unsigned)((a.Np + 3) / 4)), dim3(256), 0, s, a.part_val, (int)N,
+                     a.Np, k, const_cast<float*>(a.tau0), const_cast<float*>(a.thr));
   err = hipMemsetAsync(a.cnt, 0, (size_t)N * (kSplits + 1) * 4, s);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL((knn_screen_kernel<true, BIG>), dim3(blocks), dim3(S::kThreads), lds_emit, s, a);
+  if (v8) {
+    err = hipMemsetAsync(a.pool_ctl, 0, ((size_t)a.pool_chunks + 1) * 4, s);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL((knn_screen8_kernel<true>), dim3(blocks), dim3(512), lds_emit, s, a);
+    hipLaunchKernelGGL(knn_pool_scatter_kernel, dim3((unsigned)a.pool_chunks), dim3(kChunk), 0, s, a.pool, a.pool_ctl, a.cap_r, a.cap_c,
+                       a.cnt, a.buf);
+  } else {
+    hipLaunchKernelGGL((knn_screen_kernel<true, BIG>), dim3(blocks), dim3(S::kThreads), lds_emit, s, a);
+  }
   return hipGetLastError();
 }
 
@@ -650,7 +1242,11 @@ hipError_t knn_cosine_topk_screened(const float* Xn, int64_t ld, int64_t N, int6
   ScreenArgs a;
   a.Xb = Xb, a.N = (int)N, a.Np = L.Np, a.Dp = L.Dp, a.k = k, a.cap_r = L.cap_r, a.cap_c = L.cap_c;
   a.part_val = part, a.tau0 = tau0, a.cnt = cnt, a.buf = buf;
+  a.thr = reinterpret_cast<const float*>(ws + L.thr);
   a.sym = L.sym ? 1 : 0;
+  a.pool = L.pool_chunks ? reinterpret_cast<int4*>(ws + L.pool) : nullptr;
+  a.pool_ctl = reinterpret_cast<int32_t*>(ws + L.pool_ctl);
+  a.pool_chunks = L.pool_chunks;
   hipError_t err = L.big ? launch_screen<true>(a, N, k, s) : launch_screen<false>(a, N, k, s);
   if (err != hipSuccess) return err;
   const dim3 rgrid((unsigned)((N + 3) / 4));

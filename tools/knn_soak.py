@@ -34,11 +34,15 @@ def data(kind, N, D):
 
 bad = 0
 cases = 0
-for N in (1536, 2500, 4097, 9000, 20011, 26000, 45000):
-    for D in (8, 64, 200, 768):
-        for k in (1, 4, 16, 33, 64):
+# --big: only the sizes of the 256 x 256 screen tiles (N >= 49152: the phase-interleaved LDS-DMA kernel up to k = 16 and 2+ K
+# chunks, the register-staged one beyond)
+grid = ((49152, 50007, 66000), (40, 72, 200, 768), (1, 4, 16, 33)) if "--big" in sys.argv else \
+    ((1536, 2500, 4097, 9000, 20011, 26000, 45000), (8, 64, 200, 768), (1, 4, 16, 33, 64))
+for N in grid[0]:
+    for D in grid[1]:
+        for k in grid[2]:
             for kind in ("iso", "clustered", "lowrank", "dups", "zeros", "heavy"):
-                if N * D > 20011 * 768 and kind not in ("iso", "clustered"):
+                if N * D > 20011 * 768 and kind not in ("iso", "clustered") and "--big" not in sys.argv:
                     continue
                 if not ops.knn_cosine_supported(N, D, k):
                     continue
