@@ -374,16 +374,20 @@ __global__ __launch_bounds__(Shape<BIG>::kThreads, 2) void knn_screen_kernel(Scr
 //   * stages with `global_load_lds_dwordx4` (no VGPRs, no store pass): the LDS image of a wave-instruction is lane-linear
 //     (8 rows x 128 B), so the XOR swizzle sits on the per-lane SOURCE piece and on the fragment reads;
 //   * cuts a K chunk into 4 UNITS of 16 KB — U0 / U2 = the candidate rows each wave needs for its first / second
-//     32-candidate sub-tile, U1 / U3 = the query rows for its first / second 64-query sub-tile — and a chunk's work into 4
-//     PHASES, one 64 x 32 quadrant of the wave's 128 x 64 tile each (16 `v_mfma_f32_16x16x32_bf16`): phase 1 reads U1 (8
-//     `ds_read_b128`), phase 2 U2 (4), phase 3 U3 (8), phase 4 the NEXT chunk's U0 (4) into the registers phase 3 has freed;
-//   * every phase = [fragment reads, 2 LDS-DMA instructions of a later unit, `s_waitcnt vmcnt(8)`] barrier [16 MFMAs] barrier
-//     (at a tile's end: [DMA, the thresholding of the quadrant finished one phase ago, reads]).  Waves 4-7 run ONE barrier behind waves 0-3, so on every SIMD one
-//     wave multiplies while its partner loads (MI355X_MICROARCH 'Two waves per SIMD');
-//   * the DMA of unit g = 4 chunk + u is issued in phase g - 5 and waited for (counted, never 0: four units stay in flight
-//     across every barrier) at the end of the phase before its first read; a slot is refilled no earlier than two phases
-//     after its last read (the staggered waves' reads retire one barrier later).  The stream of units runs across tile
-//     boundaries; past the end it re-reads the last chunk, so the count never changes, and it is drained before exit.
+//     32-candidate sub-tile, U1 / U3 = the query rows for its first / second 64-query sub-tile — and a chunk's work into 2
+//     PHASES of 32 `v_mfma_f32_16x16x32_bf16`, two 64 x 32 quadrants of the wave's 128 x 64 tile each: phase A = the first
+//     query sub-tile against both candidate sub-tiles (reads U0, U1, U2: 16 `ds_read_b128`), phase B = the second (reads U3: 8;
+//     the candidate fragments stay in registers);
+//   * every phase = [fragment reads, LDS-DMA of the NEXT chunk (its U0-U2 in phase A, its U3 in phase B), a counted
+//     `s_waitcnt vmcnt`] barrier [32 MFMAs] barrier (at a tile's end: [DMA, the thresholding of the two quadrants finished one
+//     phase ago, reads]).  Waves 4-7 run ONE barrier behind waves 0-3, so on every SIMD one wave multiplies while its partner
+//     loads (MI355X_MICROARCH 'Two waves per SIMD'; measured: worth 10 %);
+//   * a unit is issued two phases before its first read and waited for (counted, never 0 in the loop: `vmcnt(6)` after phase A's
+//     issue leaves the next chunk's six instructions in flight across the barriers, `vmcnt(2)` after phase B's its U3) at the end
+//     of the phase before that read; a slot is refilled no earlier than two phases after its last read (the staggered waves'
+//     reads retire one barrier later).  The stream runs across tile boundaries; past the end it re-reads the last chunk, so the
+//     counts never change, and it is drained before exit.  (First form: 4 phases of 16 MFMAs, units five phases ahead — 3 % slower;
+//     the DMA instructions spread between the MFMAs, one per 32 cycles and CU: 5 % slower: profiles/r04_knn_lab_notes.md.)
 // A = candidates, B = queries as before: a lane's 4 results per MFMA belong to ONE query (its column), 4 candidate rows.
 constexpr int kUnitBytes = 16384;            // 128 rows x 128 B
 constexpr int kBufBytes = 4 * kUnitBytes;    // one K chunk of both tiles
@@ -601,7 +605,6 @@ __device__ __forceinline__ void screen8_quadrant(floatx4 (&acc)[8][4], float (&t
 template <bool EMIT>
 __global__ __launch_bounds__(512, 2) void knn_screen8_kernel(ScreenArgs a) {
 #define S8_BAR() DGMI_PHASE_BARRIER()
-#define S8_VMW() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
   extern __shared__ __align__(16) unsigned char screen_lds[];
   unsigned char* const smem = screen_lds;                                   // [2 buffers][4 units][128 rows][128 B]
   float* ethr_c = reinterpret_cast<float*>(smem + 2 * kBufBytes);           // EMIT, triangular: [2][256] thresholds of candidate rows
@@ -699,166 +702,129 @@ __global__ __launch_bounds__(512, 2) void knn_screen8_kernel(ScreenArgs a) {
   }
 
   if (total > 0) {  // (workgroup-uniform)
-  // chunk cursors: (tile, kc) = the chunk being multiplied; byte offsets of the next chunk's rows (o1q, o1c) and of the one
-  // after (o2q, o2c), clamped at the last chunk
+  // chunk cursors: (tile, kc) = the chunk being multiplied; byte offsets of the next chunk's rows (o1q, o1c), clamped at the
+  // last chunk
   int tile = t0, kc = 0, ci = 0;
   const int64_t oq0 = (int64_t)q_tile * kT * rowB, oc0 = (int64_t)t0 * kT * rowB;
   const int64_t tile_step = (int64_t)tstep * kT * rowB - (int64_t)(nK - 1) * 128;
-  int k1 = 0, k2;
-  int64_t o1q = oq0, o1c = oc0, o2q, o2c;
-#define DGMI_S8_ADVANCE(ki_, oqi_, oci_, ko_, oqo_, oco_, idx_) \
-  {                                                             \
-    ko_ = ki_, oqo_ = oqi_, oco_ = oci_;                        \
-    if ((idx_) + 1 < total) {                                   \
-      if (ki_ + 1 == nK)                                        \
-        ko_ = 0, oqo_ = oqi_ - (int64_t)(nK - 1) * 128, oco_ = oci_ + tile_step; \
-      else                                                      \
-        ko_ = ki_ + 1, oqo_ = oqi_ + 128, oco_ = oci_ + 128;    \
-    }                                                           \
+  int k1 = 0;
+  int64_t o1q = oq0, o1c = oc0;
+#define DGMI_S8_ADVANCE(idx_)                                                   \
+  {                                                                             \
+    if ((idx_) + 1 < total) {                                                   \
+      if (k1 + 1 == nK)                                                         \
+        k1 = 0, o1q = o1q - (int64_t)(nK - 1) * 128, o1c = o1c + tile_step;     \
+      else                                                                      \
+        k1 = k1 + 1, o1q = o1q + 128, o1c = o1c + 128;                          \
+    }                                                                           \
   }
-  // prologue: units 0..5 (chunk 0 whole, chunk 1's U0, U1)
+  // prologue: chunk 0 whole; U0-U2 must have landed before the first reads, U3 before phase B
   DGMI_S8_ISSUE(0, oq0, oc0, 0);
   DGMI_S8_ISSUE(1, oq0, oc0, 0);
   DGMI_S8_ISSUE(2, oq0, oc0, 0);
   DGMI_S8_ISSUE(3, oq0, oc0, 0);
-  DGMI_S8_ADVANCE(k1, o1q, o1c, k1, o1q, o1c, 0);
-  DGMI_S8_ADVANCE(k1, o1q, o1c, k2, o2q, o2c, 1);
-  DGMI_S8_ISSUE(0, o1q, o1c, 1);
-  DGMI_S8_ISSUE(1, o1q, o1c, 1);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  DGMI_S8_ADVANCE(0);
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   S8_BAR();
   if (wave >= 4) S8_BAR();  // waves 4-7 run one barrier behind
 
   bf16x8 qf[4][2], cf0[2][2], cf1[2][2];
   int tcount = 0;           // tiles finished by this workgroup
-  int prev_tile = tile;     // the tile whose last quadrant is still to be thresholded
-  // chunk 0's first candidate sub-tile (every later one is read in phase 4 of the chunk before)
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    DGMI_S8_RD(cf1[m][0], c_rd0 + m * 2048 + sl0);
-    DGMI_S8_RD(cf1[m][1], c_rd0 + m * 2048 + sl1);
-  }
+  int prev_tile = tile;     // the tile whose second-half quadrants are still to be thresholded
   for (; ci < total; ++ci) {
-    const int bo = (ci & 1) * kBufBytes;
+    const int bo = (ci & 1) * kBufBytes, bn = ((ci + 1) & 1);
     const bool first = kc == 0, last = kc == nK - 1;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) cf0[m][0] = cf1[m][0], cf0[m][1] = cf1[m][1];
     // A load part is [fragment reads, this phase's LDS-DMA] — the reads first: their latency passes while the DMA is issued.
-    // Where a quadrant was finished one phase ago (a tile's last chunk and the phase after it) the order is [DMA, thresholding
-    // of that quadrant, reads]: the fragment registers are dead until the reads, and the epilogue with the list filing inside it
-    // needs them (a spilled register costs a scratch reload, a vector-memory operation whose wait drains the DMA queue).
+    // Where quadrants were finished one phase ago (a tile's last chunk and the phase after it) the order is [DMA, thresholding
+    // of those quadrants, reads]: the fragment registers are dead until the reads, and the epilogue with the list filing inside
+    // it needs them (a spilled register costs a scratch reload, a vector-memory operation whose wait drains the DMA queue).
 #define S8_FENCE() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#define S8_READS_1()                                                 \
-  {                                                                  \
-    _Pragma("unroll") for (int n = 0; n < 4; ++n) {                  \
-      DGMI_S8_RD(qf[n][0], bo + q_rd0 + n * 2048 + sl0);             \
-      DGMI_S8_RD(qf[n][1], bo + q_rd0 + n * 2048 + sl1);             \
-    }                                                                \
-  }
-  /* the NEXT chunk's first candidate sub-tile, into the registers of the second (dead since phase 3's MFMAs) */ \
-
-#define S8_READS_4()                                                               \
+#define S8_READS_A()                                                               \
   {                                                                                \
     _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                \
-      DGMI_S8_RD(cf1[m][0], (bo ^ kBufBytes) + c_rd0 + m * 2048 + sl0);            \
-      DGMI_S8_RD(cf1[m][1], (bo ^ kBufBytes) + c_rd0 + m * 2048 + sl1);            \
+      DGMI_S8_RD(cf0[m][0], bo + c_rd0 + m * 2048 + sl0);                          \
+      DGMI_S8_RD(cf0[m][1], bo + c_rd0 + m * 2048 + sl1);                          \
     }                                                                              \
-  }
-#define S8_READS_2()                                                               \
-  {                                                                                \
+    _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                \
+      DGMI_S8_RD(qf[n][0], bo + q_rd0 + n * 2048 + sl0);                           \
+      DGMI_S8_RD(qf[n][1], bo + q_rd0 + n * 2048 + sl1);                           \
+    }                                                                              \
     _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                \
       DGMI_S8_RD(cf1[m][0], bo + 2 * kUnitBytes + c_rd0 + m * 2048 + sl0);         \
       DGMI_S8_RD(cf1[m][1], bo + 2 * kUnitBytes + c_rd0 + m * 2048 + sl1);         \
     }                                                                              \
   }
-#define S8_READS_3()                                                               \
+#define S8_READS_B()                                                               \
   {                                                                                \
     _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                \
       DGMI_S8_RD(qf[n][0], bo + 2 * kUnitBytes + q_rd0 + n * 2048 + sl0);          \
       DGMI_S8_RD(qf[n][1], bo + 2 * kUnitBytes + q_rd0 + n * 2048 + sl1);          \
     }                                                                              \
   }
-    // ---- phase 1: quadrant (Q0, C0) ----
+#define S8_ISSUE_A()                         \
+  {                                          \
+    DGMI_S8_ISSUE(0, o1q, o1c, bn);          \
+    DGMI_S8_ISSUE(1, o1q, o1c, bn);          \
+    DGMI_S8_ISSUE(2, o1q, o1c, bn);          \
+  }
+    // ---- phase A: quadrants (Q0, C0), (Q0, C1); reads U0, U1, U2; DMA of the next chunk's U0, U1, U2 ----
     if (first && ci > 0) {
-      DGMI_S8_ISSUE(2, o1q, o1c, (ci + 1) & 1);
+      S8_ISSUE_A();
+      screen8_quadrant<EMIT, 1, 1>(acc, top, L, W, ovf, a, prev_tile, (tcount - 1) & 1);
       screen8_quadrant<EMIT, 1, 0>(acc, top, L, W, ovf, a, prev_tile, (tcount - 1) & 1);
-      if (EMIT && W.g_cnt > 0) screen8_flush(a, L, W);  // the finished tile's groups (its thresholds stay until this tile's phase 3)
+      if (EMIT && W.g_cnt > 0) screen8_flush(a, L, W);  // the finished tile's groups (its thresholds stay two more phases)
       S8_FENCE();
-      S8_READS_1();
+      S8_READS_A();
     } else {
-      S8_READS_1();
-      DGMI_S8_ISSUE(2, o1q, o1c, (ci + 1) & 1);
+      S8_READS_A();
+      S8_ISSUE_A();
     }
-    S8_VMW();
-    S8_BAR();
-    DGMI_S8_MMA(0, 0, cf0);
-    S8_BAR();
-    // ---- phase 2: quadrant (Q0, C1) ----
-    if (last) {
-      DGMI_S8_ISSUE(3, o1q, o1c, (ci + 1) & 1);
-      screen8_quadrant<EMIT, 0, 0>(acc, top, L, W, ovf, a, tile, tcount & 1);
-      S8_FENCE();
-      S8_READS_2();
-    } else {
-      S8_READS_2();
-      DGMI_S8_ISSUE(3, o1q, o1c, (ci + 1) & 1);
-    }
-    S8_VMW();
-    S8_BAR();
-    DGMI_S8_MMA(0, 2, cf1);
-    S8_BAR();
-    // ---- phase 3: quadrant (Q1, C1) ----
-    if (last) {
-      DGMI_S8_ISSUE(0, o2q, o2c, ci & 1);
-      screen8_quadrant<EMIT, 0, 1>(acc, top, L, W, ovf, a, tile, tcount & 1);
-      S8_FENCE();
-      S8_READS_3();
-    } else {
-      S8_READS_3();
-      DGMI_S8_ISSUE(0, o2q, o2c, ci & 1);
-    }
-    if (EMIT && first && a.sym && wave < 4 && ci + nK < total) {
-      // the NEXT tile's row thresholds, by LDS-DMA like everything else (4 B per lane, one instruction in each of waves 0-3:
-      // their extra entry in the queue only makes the counted waits stricter); read from the next tile's last chunk on
+    if (EMIT && kc == 1 && a.sym && wave < 4 && ci - 1 + nK < total) {
+      // the NEXT tile's row thresholds, by LDS-DMA like everything else (4 B per lane, one instruction in each of waves 0-3);
+      // their buffer was last read two phases ago, they are read from the next tile's last chunk on
       int ln_ = lane;
       asm volatile("" : "+v"(ln_));  // (the address is made here, not carried through the loop)
       const float* src_ = a.thr + (int64_t)(tile + tstep) * kT + wave * 64 + ln_;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_,
                                        (__attribute__((address_space(3))) void*)(ethr_c + ((tcount + 1) & 1) * 256 + wave * 64), 4, 0, 0);
+      asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // U3 of this chunk has landed; the six of the next and this one fly
+    } else {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // U3 of this chunk has landed; the six of the next chunk fly
     }
-    S8_VMW();
+    S8_BAR();
+    DGMI_S8_MMA(0, 0, cf0);
+    DGMI_S8_MMA(0, 2, cf1);
+    S8_BAR();
+    // ---- phase B: quadrants (Q1, C1), (Q1, C0); reads U3; DMA of the next chunk's U3 ----
+    if (last) {
+      DGMI_S8_ISSUE(3, o1q, o1c, bn);
+      screen8_quadrant<EMIT, 0, 0>(acc, top, L, W, ovf, a, tile, tcount & 1);
+      screen8_quadrant<EMIT, 0, 1>(acc, top, L, W, ovf, a, tile, tcount & 1);
+      S8_FENCE();
+      S8_READS_B();
+    } else {
+      S8_READS_B();
+      DGMI_S8_ISSUE(3, o1q, o1c, bn);
+    }
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // U0-U2 of the next chunk have landed
     S8_BAR();
     DGMI_S8_MMA(4, 2, cf1);
-    S8_BAR();
-    // ---- phase 4: quadrant (Q1, C0) ----
-    if (last) {
-      DGMI_S8_ISSUE(1, o2q, o2c, ci & 1);
-      screen8_quadrant<EMIT, 1, 1>(acc, top, L, W, ovf, a, tile, tcount & 1);
-      S8_FENCE();
-      S8_READS_4();
-    } else {
-      S8_READS_4();
-      DGMI_S8_ISSUE(1, o2q, o2c, ci & 1);
-    }
-    S8_VMW();
-    S8_BAR();
     DGMI_S8_MMA(4, 0, cf0);
     S8_BAR();
 #undef S8_FENCE
-#undef S8_READS_1
-#undef S8_READS_2
-#undef S8_READS_3
-#undef S8_READS_4
+#undef S8_READS_A
+#undef S8_READS_B
+#undef S8_ISSUE_A
 
     if (last) prev_tile = tile, ++tcount;
     if (ci + 1 < total) {
       if (last) kc = 0, tile += tstep; else ++kc;
     }
-    k1 = k2, o1q = o2q, o1c = o2c;
-    DGMI_S8_ADVANCE(k1, o1q, o1c, k2, o2q, o2c, ci + 2);
+    DGMI_S8_ADVANCE(ci + 1);
   }
   if (wave < 4) S8_BAR();  // waves 0-3 end one barrier ahead
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may be in flight when the workgroup's LDS is released
+  screen8_quadrant<EMIT, 1, 1>(acc, top, L, W, ovf, a, prev_tile, (tcount - 1) & 1);
   screen8_quadrant<EMIT, 1, 0>(acc, top, L, W, ovf, a, prev_tile, (tcount - 1) & 1);
   if (EMIT && W.g_cnt > 0) screen8_flush(a, L, W);
   }
@@ -896,7 +862,6 @@ __global__ __launch_bounds__(512, 2) void knn_screen8_kernel(ScreenArgs a) {
   }
 }
 #undef S8_BAR
-#undef S8_VMW
 #undef DGMI_S8_ISSUE1
 #undef DGMI_S8_ISSUE
 #undef DGMI_S8_FRAG
