@@ -37,6 +37,8 @@ Tuning& tuning() {
     v.select_window_min = env_ll("DGMI_SELECT_WINDOW_MIN", 0);
     v.select_narrow_window = env_ll("DGMI_SELECT_NARROW_WINDOW", 0) != 0 ? 1 : 0;
     v.sort_plain_tiles = env_ll("DGMI_SORT_PLAIN_TILES", 0) != 0 ? 1 : 0;
+    v.knn_screen_first = env_ll("DGMI_KNN_SCREEN_V1", 0) != 0 ? 1 : 0;
+    v.knn_pool_chunks = env_ll("DGMI_KNN_POOL_CHUNKS", 0);
     return v;
   }();
   return t;
@@ -57,6 +59,8 @@ DGMI_API int dgmi_set_tuning(const char* name, int64_t value) {
   else if (strcmp(name, "select_window_min") == 0) t.select_window_min = value;
   else if (strcmp(name, "select_narrow_window") == 0) t.select_narrow_window = value != 0;
   else if (strcmp(name, "sort_plain_tiles") == 0) t.sort_plain_tiles = value != 0;
+  else if (strcmp(name, "knn_screen_first") == 0) t.knn_screen_first = value != 0;
+  else if (strcmp(name, "knn_pool_chunks") == 0) t.knn_pool_chunks = value;
   else return DGMI_ERR_INVALID_ARG;
   return DGMI_OK;
 }

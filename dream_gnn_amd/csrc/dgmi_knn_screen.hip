@@ -39,6 +39,7 @@
 #include <stdlib.h>
 
 #include "dgmi_kernels.h"
+#include "dgmi_tuning.h"
 
 namespace dgmi {
 namespace {
@@ -629,6 +630,10 @@ __global__ __launch_bounds__(512, 2) void knn_screen8_kernel(ScreenArgs a) {
     t0 = stride * split;
     tstep = stride * kSplits;
     nt = n_tiles > t0 ? (n_tiles - t0 + tstep - 1) / tstep : 0;
+    // the same number of tiles for every split (7 / 6 / 6 ... at N = 100 000 made the pass as long as its 7-tile workgroups):
+    // the few sampled tiles beyond a multiple of the splits are left out — any sample of distinct candidates bounds tau
+    const int sampled = (n_tiles + stride - 1) / stride;
+    if (sampled >= 2 * kSplits && nt > sampled / kSplits) nt = sampled / kSplits;
   }
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1171,6 +1176,7 @@ ScreenLayout screen_layout(int64_t N, int64_t D, int k) {
   // candidates, both directions of the triangular sweep, the 2 eps margin): room for 32 k + 96 per query, in chunks (each
   // wave of each workgroup holds one partly filled chunk: the 2048)
   L.pool_chunks = L.big && k <= 16 ? (int)(((size_t)N * (32 * k + 96) + kChunk - 1) / kChunk) + 2048 : 0;
+  if (L.pool_chunks != 0 && tuning().knn_pool_chunks > 0) L.pool_chunks = (int)tuning().knn_pool_chunks;  // (test: a pool that runs out)
   L.pool = at, at += align256((size_t)L.pool_chunks * kChunk * 16);
   L.pool_ctl = at, at += align256(L.pool_chunks ? ((size_t)L.pool_chunks + 1) * 4 : 0);
   L.total = at;
@@ -1182,12 +1188,9 @@ hipError_t launch_screen(const ScreenArgs& a, int64_t N, int k, hipStream_t s) {
   using S = Shape<BIG>;
   const int n_groups = (a.Np / S::kTile + 7) / 8;
   const unsigned blocks = (unsigned)(8 * ((n_groups + 7) / 8) * 64);
-  // the 256 x 256 shape runs the phase-interleaved LDS-DMA kernel up to k = 16 (DGMI_KNN_SCREEN_V1=1: the first kernel, for
+  // the 256 x 256 shape runs the phase-interleaved LDS-DMA kernel up to k = 16 (tuning knn_screen_first: the first kernel, for
   // A/B tools); beyond, a quadrant keeps too many pairs for its group lists and the first kernel stays
-  static const bool v1 = [] {
-    const char* e = getenv("DGMI_KNN_SCREEN_V1");
-    return e != nullptr && e[0] == '1';
-  }();
+  const bool v1 = tuning().knn_screen_first != 0;
   const bool v8 = BIG && a.pool != nullptr && !v1 && a.Dp >= 2 * kSK;  // (one-chunk rows: the threshold DMA would arrive late)
   const size_t lds_sample = v8 ? 2 * kBufBytes : 2 * S::kStage;
   const size_t lds_emit = v8 ? 2 * kBufBytes + 3072 + 8 * kGrpCap * kGrpBytes : 2 * S::kStage + 2 * S::kTile * 4;

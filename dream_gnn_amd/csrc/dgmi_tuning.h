@@ -15,6 +15,8 @@ struct Tuning {
   int64_t select_window_min = 0;    // DGMI_SELECT_WINDOW_MIN: shortest list that takes the window passes
   int select_narrow_window = 0;     // DGMI_SELECT_NARROW_WINDOW: a window that misses (forces the take-over path; test)
   int sort_plain_tiles = 0;         // DGMI_SORT_PLAIN_TILES: record sort with tile = blockIdx.x instead of the XCD-aware order
+  int knn_screen_first = 0;         // DGMI_KNN_SCREEN_V1: the first (register-staged) 256 x 256 screen kernel instead of the LDS-DMA one (A/B tools)
+  int64_t knn_pool_chunks = 0;      // DGMI_KNN_POOL_CHUNKS: chunks of the screen's record pool (a pool that runs out: the direct appends; test)
 };
 
 Tuning& tuning();  // dgmi_api.hip

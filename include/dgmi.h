@@ -414,9 +414,11 @@ DGMI_API int dgmi_probe_row_gather_f32(const float* table, int64_t n_rows, int64
  * Launch-parameter overrides for the measurement tools (the scripts under tools/; not part of the product path).  The built-in
  * choices are measured ones; a tool that wants to A/B one inside a single process sets it here.
  * Names: "sliced_rows", "sliced_touch_lead" (-1 = built-in, 0 = no touch-ahead), "sliced_lpr", "sliced_no_off32",
- * "sliced_chunk_rows", "select_window_min", "select_narrow_window", "sort_plain_tiles"; 0 restores the built-in choice (-1 for
+ * "sliced_chunk_rows", "select_window_min", "select_narrow_window", "sort_plain_tiles", "knn_screen_first", "knn_pool_chunks"
+ * (change the latter only between a workspace-size query and nothing: the size depends on it); 0 restores the built-in choice (-1 for
  * sliced_touch_lead).  The same values are read from the environment variables DGMI_SLICED_ROWS, DGMI_SLICED_PF,
- * DGMI_SLICED_LPR, DGMI_NO_OFF32, DGMI_SLICED_CHUNK_ROWS, DGMI_SELECT_WINDOW_MIN, DGMI_SELECT_NARROW_WINDOW, DGMI_SORT_PLAIN_TILES ONCE, when
+ * DGMI_SLICED_LPR, DGMI_NO_OFF32, DGMI_SLICED_CHUNK_ROWS, DGMI_SELECT_WINDOW_MIN, DGMI_SELECT_NARROW_WINDOW, DGMI_SORT_PLAIN_TILES,
+ * DGMI_KNN_SCREEN_V1, DGMI_KNN_POOL_CHUNKS ONCE, when
  * the library first needs them; no launch reads the environment.  Not thread-safe against concurrent launches.
  */
 DGMI_API int dgmi_set_tuning(const char* name /* host */, int64_t value);

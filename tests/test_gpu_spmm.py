@@ -803,6 +803,33 @@ def test_screened_knn_recomputes_overflowing_rows_exactly(dev):
         assert all(len(set(r.tolist())) == k for r in nbr[2990:3410].cpu())
 
 
+def test_screened_knn_pool_that_runs_out_and_first_kernel_agree(dev):
+    """(r4, f4) The 256 x 256 LDS-DMA screen kernel files what it keeps into a pool of record chunks; with the pool cut to a
+    sliver (tuning knob) almost every record takes the direct-append fallback instead — the answer is the same exact top-k,
+    and the same as the first (register-staged) kernel's."""
+    from dream_gnn_amd import _lib, ops
+
+    N, D, k = 50000, 96, 5
+    gen = torch.Generator().manual_seed(77)
+    X = torch.randn(N, D, generator=gen)
+    X[100:140] = X[100] + 1e-3 * torch.randn(40, D, generator=gen)  # a small cluster: no region overflows, lists get busy
+    xn = (X / X.norm(dim=1, keepdim=True)).to(dev)
+    want = ops.knn_cosine_topk(xn, k).long()
+    rows = torch.cat([torch.arange(2000), torch.arange(N - 1000, N)]).to(dev)
+    sim = xn[rows].double() @ xn.double().t()
+    ref = torch.topk(sim, k, dim=1).values
+    assert float((torch.gather(sim, 1, want[rows]) - ref).abs().max()) <= 2e-6
+    for knob, value in (("knn_pool_chunks", 48), ("knn_screen_first", 1)):
+        _lib.set_tuning(knob, value)
+        try:
+            got = ops.knn_cosine_topk(xn, k).long()
+        finally:
+            _lib.set_tuning(knob, 0)
+        assert float((torch.gather(sim, 1, got[rows]) - ref).abs().max()) <= 2e-6, knob
+        same = (got == want).all(dim=1).float().mean()
+        assert float(same) > 0.999, knob  # (near-ties may pick another id)
+
+
 def test_compaction_invert_and_nested_descriptions_randomized(oracle, dev):
     """(r3) The on-the-fly dropout path after round 3 — survivors compacted to the front of every 64-id batch, INVERTED
     descriptions (the complement form subtracts a relation's dropped edges), several descriptions over the same edges

@@ -1,6 +1,7 @@
 """(f4) the 256 x 256 screen kernels: correctness of sampled rows against a float64 brute force on shapes that cover
 K chunk counts 1 / 2 / 3 / 12, both sweeps and the overflow paths, then timing.  DGMI_KNN_SCREEN_V1=1 in the environment
-runs the first (register-staged) 256 x 256 kernel instead of the phase-interleaved LDS-DMA one."""
+(read once into the library's tuning, also `_lib.set_tuning("knn_screen_first", 1)`) runs the first (register-staged) 256 x 256
+kernel instead of the phase-interleaved LDS-DMA one."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
