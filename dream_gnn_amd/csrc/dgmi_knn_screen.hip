@@ -1175,7 +1175,8 @@ ScreenLayout screen_layout(int64_t N, int64_t D, int k) {
   // the phase-interleaved 256 x 256 kernel (k <= 16) keeps ~ 20 k pairs per query (tau' comes from an eighth of the
   // candidates, both directions of the triangular sweep, the 2 eps margin): room for 32 k + 96 per query, in chunks (each
   // wave of each workgroup holds one partly filled chunk: the 2048)
-  L.pool_chunks = L.big && k <= 16 ? (int)(((size_t)N * (32 * k + 96) + kChunk - 1) / kChunk) + 2048 : 0;
+  const size_t want_chunks = ((size_t)N * (32 * k + 96) + kChunk - 1) / kChunk + 2048;
+  L.pool_chunks = L.big && k <= 16 ? (int)(want_chunks < ((size_t)1 << 30) ? want_chunks : ((size_t)1 << 30)) : 0;
   if (L.pool_chunks != 0 && tuning().knn_pool_chunks > 0) L.pool_chunks = (int)tuning().knn_pool_chunks;  // (test: a pool that runs out)
   L.pool = at, at += align256((size_t)L.pool_chunks * kChunk * 16);
   L.pool_ctl = at, at += align256(L.pool_chunks ? ((size_t)L.pool_chunks + 1) * 4 : 0);
