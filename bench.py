@@ -437,6 +437,29 @@ def variants(torch, dev, ops):
     return out
 
 
+def graph_construction(torch, dev, ops):
+    """Context beside the judged step: the one-time construction of config 4's kNN similarity graphs (row f4, reference
+    data_loader.py:312-344: cosine top-k of 768-d rows) — the neighbour search alone, ms per call at N = 100 000."""
+    from dream_gnn_amd import ops as O
+
+    out = {"what": "dgmi_knn_cosine_topk_f32 on random unit rows, N = 100000, D = 768; ms per search (median of 3)"}
+    x = torch.randn(100_000, 768, device=dev)
+    xn = x / x.norm(dim=1, keepdim=True)
+    for k in (4, 64):
+        O.knn_cosine_topk(xn, k)
+        ts = []
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            O.knn_cosine_topk(xn, k)
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        out["knn_search_ms_k%d" % k] = round(sorted(ts)[1], 3)
+    out["full_rectangle_TFLOPs"] = round(2.0 * 100_000 * 100_000 * 768 / 1e12, 2)
+    return out
+
+
 def edge_dropped_step(torch, dev, ops, layers=3):
     """The second headline: the step of `run_step` with ALL 8 products edge-dropped, as every training iteration of the
     reference runs them (train.py:267: augmentation is unconditional; augmentation.py:48-52,114-118: keep
@@ -969,6 +992,10 @@ def main():
                 out["edge_dropped_step"] = edge_dropped_step(torch, dev, ops)
             except Exception as exc:  # noqa: BLE001
                 out["edge_dropped_step"] = {"error": repr(exc)}
+            try:
+                out["graph_construction"] = graph_construction(torch, dev, ops)
+            except Exception as exc:  # noqa: BLE001
+                out["graph_construction"] = {"error": repr(exc)}
             out["model_steps"] = model_steps_in_child()
         if world == 1 and not args.no_cpu_baseline:
             progress("cpu_baseline (bounded sample on the host cores)")
