@@ -6,7 +6,7 @@ import torch
 from dream_gnn_amd import ops
 
 dev = torch.device("cuda:0")
-gen = torch.Generator(device=dev).manual_seed(1234)
+gen = torch.Generator(device=dev).manual_seed(4321 if "--big2" in sys.argv else 1234)
 
 
 def data(kind, N, D):
@@ -36,13 +36,14 @@ bad = 0
 cases = 0
 # --big: only the sizes of the 256 x 256 screen tiles (N >= 49152: the phase-interleaved LDS-DMA kernel up to k = 16 and 2+ K
 # chunks, the register-staged one beyond)
-grid = ((49152, 50007, 66000), (40, 72, 200, 768), (1, 4, 16, 33)) if "--big" in sys.argv else \
+grid = ((55555, 80000, 131072), (96, 384, 768, 1024), (1, 2, 8, 16)) if "--big2" in sys.argv else \
+    ((49152, 50007, 66000), (40, 72, 200, 768), (1, 4, 16, 33)) if "--big" in sys.argv else \
     ((1536, 2500, 4097, 9000, 20011, 26000, 45000), (8, 64, 200, 768), (1, 4, 16, 33, 64))
 for N in grid[0]:
     for D in grid[1]:
         for k in grid[2]:
             for kind in ("iso", "clustered", "lowrank", "dups", "zeros", "heavy"):
-                if N * D > 20011 * 768 and kind not in ("iso", "clustered") and "--big" not in sys.argv:
+                if N * D > 20011 * 768 and kind not in ("iso", "clustered") and "--big" not in sys.argv and "--big2" not in sys.argv:
                     continue
                 if not ops.knn_cosine_supported(N, D, k):
                     continue
