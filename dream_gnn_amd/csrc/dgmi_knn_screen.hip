@@ -427,9 +427,10 @@ __device__ __forceinline__ floatx4 lds_read_f4(uint32_t addr) {
 // four phases, and a returning atomic drains the queue).  A lane whose 8 scores of one (query, quadrant) hold a candidate for
 // either direction writes them as a GROUP (48 B: 8-B header + the two accumulator registers as they stand) into its WAVE's list in
 // LDS: position by ballot rank, cursor in a scalar register, no atomic, no wait.  Once per tile the wave files its list: one
-// lane per (group, score), exact comparison, survivors ranked by ballot into 16-B records of the wave's current pool chunk
-// (global, 256 records, drawn from one cursor with a returning atomic every ~20 tiles) — two or three coalesced stores per
-// tile and wave.  Slot allocation in the queries' buffers is knn_pool_scatter_kernel's.
+// lane per (group, score), exact comparison; a pair for one of the workgroup's OWN queries takes its slot from the (query, split)
+// region's counter in LDS and goes straight to its place, a pair offered to a query of another tile is ranked by ballot into a
+// 16-B record of the wave's current pool chunk (global, 256 records, drawn from one cursor with a returning atomic every ~40
+// tiles) and knn_pool_scatter_kernel allocates its slot afterwards — two or three store instructions per tile and wave.
 constexpr int kGrpCap = 64;     // groups per wave list (one epilogue position can add 64)
 constexpr int kGrpBytes = 48;   // header (8 of 16 B) + 8 scores
 constexpr int kChunk = 256;     // records per pool chunk
@@ -442,6 +443,7 @@ struct Screen8Lane {
   uint32_t list;     // LDS byte address of this wave's group list
   uint32_t ethr_c;   // LDS byte address of the candidate rows' thresholds [2][256]
   uint32_t ethr_q;   // LDS byte address of the workgroup's own queries' thresholds [wq][fr][nt]: a lane's 8 are 32 B
+  uint32_t cnt_sh;   // LDS byte address of the entry counters of the workgroup's 256 (query, split) regions
 };
 struct Screen8Wave {  // wave-uniform
   int g_cnt;          // groups in the list
@@ -472,7 +474,19 @@ __device__ __forceinline__ void screen8_flush(const ScreenArgs& a, const Screen8
       asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(thr) : "v"(t_at) : "memory");
     }
     const bool hit = valid && s >= thr;  // (padding candidates carry kMasked scores, padding rows a threshold of 4)
-    const uint64_t bal = __ballot(hit);
+    // direction 1: the pair belongs to one of the workgroup's own queries, whose (query, split) region no other workgroup
+    // writes: the slot comes from the region's counter in LDS and the pair goes straight to its place
+    if (__ballot(hit && !dir2) != 0) {
+      if (hit && !dir2) {
+        uint32_t slot;
+        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(slot) : "v"(L.cnt_sh + 4u * (uint32_t)(qid & 255)), "v"(1u) : "memory");
+        if (slot < (uint32_t)L.cap_r)
+          a.buf[(int64_t)qid * L.q_slots + (int64_t)L.split * L.cap_r + slot] = make_int2(cand, __float_as_int(s));
+      }
+    }
+    // direction 2: the pair belongs to a query of ANOTHER tile: a record in the wave's pool chunk, filed by the scatter kernel
+    const bool hit2 = hit && dir2;
+    const uint64_t bal = __ballot(hit2);
     if (bal != 0) {
       const int n_hit = __popcll(bal);
       if (W.chunk < 0 || W.used + n_hit > kChunk) {  // a new chunk (the rest of the old one stays empty)
@@ -485,15 +499,14 @@ __device__ __forceinline__ void screen8_flush(const ScreenArgs& a, const Screen8
         W.chunk = c < a.pool_chunks ? c : -1;
         W.used = 0;
       }
-      if (hit) {
-        const int query = dir2 ? cand : qid, other = dir2 ? qid : cand, region = dir2 ? kSplits : L.split;
+      if (hit2) {
         if (W.chunk >= 0) {
           const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-          a.pool[(int64_t)W.chunk * kChunk + W.used + rank] = make_int4(query, other, __float_as_int(s), region);
-        } else {  // pool exhausted: straight into the query's region
-          const uint32_t slot = (uint32_t)atomicAdd(&a.cnt[(int64_t)query * (kSplits + 1) + region], 1);
-          if (slot < (uint32_t)(dir2 ? L.cap_c : L.cap_r))
-            a.buf[(int64_t)query * L.q_slots + (int64_t)region * L.cap_r + slot] = make_int2(other, __float_as_int(s));
+          a.pool[(int64_t)W.chunk * kChunk + W.used + rank] = make_int4(cand, qid, __float_as_int(s), kSplits);
+        } else {  // pool exhausted: straight into the query's column region
+          const uint32_t slot = (uint32_t)atomicAdd(&a.cnt[(int64_t)cand * (kSplits + 1) + kSplits], 1);
+          if (slot < (uint32_t)L.cap_c)
+            a.buf[(int64_t)cand * L.q_slots + (int64_t)kSplits * L.cap_r + slot] = make_int2(qid, __float_as_int(s));
         }
       }
       if (W.chunk >= 0) W.used += n_hit;
@@ -610,7 +623,8 @@ __global__ __launch_bounds__(512, 2) void knn_screen8_kernel(ScreenArgs a) {
   unsigned char* const smem = screen_lds;                                   // [2 buffers][4 units][128 rows][128 B]
   float* ethr_c = reinterpret_cast<float*>(smem + 2 * kBufBytes);           // EMIT, triangular: [2][256] thresholds of candidate rows
   float* ethr_q = ethr_c + 512;                                             // EMIT: [2][16][8] thresholds of the workgroup's queries
-  unsigned char* lists = smem + 2 * kBufBytes + 3072;                       // EMIT: [8 waves][kGrpCap][kGrpBytes]
+  uint32_t* cnt_sh = reinterpret_cast<uint32_t*>(ethr_q + 256);             // EMIT: [256] entries of the workgroup's (query, split) regions
+  unsigned char* lists = smem + 2 * kBufBytes + 4096;                       // EMIT: [8 waves][kGrpCap][kGrpBytes]
 
   constexpr int kT = 256;
   const int n_tiles = a.Np / kT;
@@ -644,7 +658,7 @@ __global__ __launch_bounds__(512, 2) void knn_screen8_kernel(ScreenArgs a) {
   L.q_slots = (int64_t)kSplits * a.cap_r + a.cap_c;
   L.lane = lane;
   L.list = lds_addr(lists) + (uint32_t)wave * (kGrpCap * kGrpBytes);
-  L.ethr_c = lds_addr(ethr_c), L.ethr_q = lds_addr(ethr_q);
+  L.ethr_c = lds_addr(ethr_c), L.ethr_q = lds_addr(ethr_q), L.cnt_sh = lds_addr(cnt_sh);
   Screen8Wave W;
   W.g_cnt = 0, W.chunk = -1, W.used = 0;
   uint32_t ovf = 0;  // EMIT: bit nt = a direction-1 group of query sub-tile nt found the list full
@@ -655,7 +669,7 @@ __global__ __launch_bounds__(512, 2) void knn_screen8_kernel(ScreenArgs a) {
 #pragma unroll
   for (int n = 0; n < 8; ++n) top[n][0] = top[n][1] = top[n][2] = top[n][3] = kUnset;
   if (EMIT) {
-    if (tid < kT) ethr_q[(((tid >> 7) * 16 + (tid & 15)) << 3) + ((tid >> 4) & 7)] = a.thr[q_tile * kT + tid];
+    if (tid < kT) ethr_q[(((tid >> 7) * 16 + (tid & 15)) << 3) + ((tid >> 4) & 7)] = a.thr[q_tile * kT + tid], cnt_sh[tid] = 0;
     if (a.sym && nt > 0 && tid < kT) ethr_c[tid] = a.thr[t0 * kT + tid];
   }
   floatx4 acc[8][4];
@@ -836,13 +850,13 @@ __global__ __launch_bounds__(512, 2) void knn_screen8_kernel(ScreenArgs a) {
 
   if (EMIT) {
     if (W.chunk >= 0 && lane == 0) a.pool_ctl[1 + W.chunk] = W.used;
-    if (ovf != 0) {
+    if (ovf != 0) {  // a direction-1 group found the list full: its query takes the exact path
 #pragma unroll
-      for (int n = 0; n < 8; ++n) {
-        const int qg = q_tile * kT + L.wq * 128 + n * 16 + L.fr;
-        if (((ovf >> n) & 1u) && qg < a.N) a.cnt[(int64_t)qg * (kSplits + 1) + split] = kOverflowMark;
-      }
+      for (int n = 0; n < 8; ++n)
+        if ((ovf >> n) & 1u) cnt_sh[L.wq * 128 + n * 16 + L.fr] = kOverflowMark;
     }
+    __syncthreads();
+    if (tid < kT && q_tile * kT + tid < a.N) a.cnt[(int64_t)(q_tile * kT + tid) * (kSplits + 1) + split] = (int32_t)cnt_sh[tid];
   } else {
     // a query's column is seen by the four lanes fr + 16 kg: lanes kg and kg ^ 1 merge their lists, so that the subsets
     // (and the layout of part_val) are those of the first 256 x 256 kernel: (split, wc, kg >> 1), four scores each
@@ -1172,11 +1186,11 @@ ScreenLayout screen_layout(int64_t N, int64_t D, int k) {
   L.cnt = at, at += align256((size_t)N * (kSplits + 1) * 4);
   L.buf = at, at += align256((size_t)N * (kSplits * L.cap_r + L.cap_c) * 8);
   L.flags = at, at += align256((size_t)N * 4);
-  // the phase-interleaved 256 x 256 kernel (k <= 16) keeps ~ 20 k pairs per query (tau' comes from an eighth of the
-  // candidates, both directions of the triangular sweep, the 2 eps margin): room for 32 k + 96 per query, in chunks (each
-  // wave of each workgroup holds one partly filled chunk: the 2048)
-  const size_t want_chunks = ((size_t)N * (32 * k + 96) + kChunk - 1) / kChunk + 2048;
-  L.pool_chunks = L.big && k <= 16 ? (int)(want_chunks < ((size_t)1 << 30) ? want_chunks : ((size_t)1 << 30)) : 0;
+  // the phase-interleaved 256 x 256 kernel keeps ~ 18 k pairs per query (tau' comes from an eighth of the candidates, the
+  // 2 eps margin); the half of them that its triangular sweep offers to the queries of OTHER tiles goes through the pool:
+  // room for 16 k + 48 per query, in chunks (each wave of each workgroup holds one partly filled chunk: the 2048)
+  const size_t want_chunks = ((size_t)N * (16 * k + 48) + kChunk - 1) / kChunk + 2048;
+  L.pool_chunks = L.big ? (int)(want_chunks < ((size_t)1 << 30) ? want_chunks : ((size_t)1 << 30)) : 0;
   if (L.pool_chunks != 0 && tuning().knn_pool_chunks > 0) L.pool_chunks = (int)tuning().knn_pool_chunks;  // (test: a pool that runs out)
   L.pool = at, at += align256((size_t)L.pool_chunks * kChunk * 16);
   L.pool_ctl = at, at += align256(L.pool_chunks ? ((size_t)L.pool_chunks + 1) * 4 : 0);
@@ -1189,12 +1203,12 @@ hipError_t launch_screen(const ScreenArgs& a, int64_t N, int k, hipStream_t s) {
   using S = Shape<BIG>;
   const int n_groups = (a.Np / S::kTile + 7) / 8;
   const unsigned blocks = (unsigned)(8 * ((n_groups + 7) / 8) * 64);
-  // the 256 x 256 shape runs the phase-interleaved LDS-DMA kernel up to k = 16 (tuning knn_screen_first: the first kernel, for
-  // A/B tools); beyond, a quadrant keeps too many pairs for its group lists and the first kernel stays
+  // the 256 x 256 shape runs the phase-interleaved LDS-DMA kernel (tuning knn_screen_first: the first kernel, for A/B tools; it
+  // also keeps the one-chunk rows, D <= 64)
   const bool v1 = tuning().knn_screen_first != 0;
   const bool v8 = BIG && a.pool != nullptr && !v1 && a.Dp >= 2 * kSK;  // (one-chunk rows: the threshold DMA would arrive late)
   const size_t lds_sample = v8 ? 2 * kBufBytes : 2 * S::kStage;
-  const size_t lds_emit = v8 ? 2 * kBufBytes + 3072 + 8 * kGrpCap * kGrpBytes : 2 * S::kStage + 2 * S::kTile * 4;
+  const size_t lds_emit = v8 ? 2 * kBufBytes + 4096 + 8 * kGrpCap * kGrpBytes : 2 * S::kStage + 2 * S::kTile * 4;
   const void* f_sample = v8 ? reinterpret_cast<const void*>(knn_screen8_kernel<false>)
                             : reinterpret_cast<const void*>(knn_screen_kernel<false, BIG>);
   const void* f_emit = v8 ? reinterpret_cast<const void*>(knn_screen8_kernel<true>)

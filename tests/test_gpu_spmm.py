@@ -733,7 +733,7 @@ def test_output_epilogue_in_every_kernel_form(dev, F, act, slope):
 @pytest.mark.parametrize("N,D,k", [(763, 768, 4), (681, 768, 4), (33, 8, 1), (1000, 64, 16), (5000, 768, 8), (32, 1024, 3),
                                    (97, 24, 13), (1536, 64, 16), (2048, 64, 1), (3001, 40, 2), (16500, 16, 5), (20000, 768, 4), (9001, 200, 16), (50001, 72, 6), (41000, 64, 12), (25000, 136, 3),
                                    (3000, 64, 64), (30000, 128, 33), (60000, 72, 40),
-                                   (50000, 40, 3), (52000, 136, 5), (49152, 768, 4), (70001, 200, 16)])
+                                   (50000, 40, 3), (52000, 136, 5), (49152, 768, 4), (70001, 200, 16), (50200, 200, 64)])
 def test_fused_knn_kernel_finds_the_k_most_similar_rows(dev, N, D, k):
     """(f4) `dgmi_knn_cosine_topk_f32` (fp32 MFMA tiles + running top-k on chip) against a brute-force
     float64 similarity matrix: every row's selected neighbours are k distinct valid ids whose
@@ -747,8 +747,8 @@ def test_fused_knn_kernel_finds_the_k_most_similar_rows(dev, N, D, k):
     assert ops.knn_cosine_supported(N, D, k)
     # N < 1536: fp32 kernel, candidates split over workgroups + merge; above: bf16 screen + exact rescoring
     # (full rectangle of tile pairs up to ~24k rows / ~41k at k > 8, triangular sweep above; 256 x 256 tiles from 49152:
-    # the phase-interleaved LDS-DMA kernel up to k = 16 with 2+ K chunks (D = 72, 136, 200, 768 here: 2, 3, 4, 12 chunks),
-    # the register-staged one beyond (k = 40) and for one-chunk rows (D = 40))
+    # the phase-interleaved LDS-DMA kernel with 2+ K chunks (D = 72, 136, 200, 768 here: 2, 3, 4, 12 chunks; k up to 64),
+    # the register-staged one for one-chunk rows (D = 40))
     nbr = ops.knn_cosine_topk(xn, k).long()
     assert nbr.shape == (N, k) and int(nbr.min()) >= 0 and int(nbr.max()) < N
     # N >= 49152 (256 x 256 screen tiles): check the first / last / a random 1500 rows against the brute force
@@ -781,7 +781,7 @@ def test_screened_knn_recomputes_overflowing_rows_exactly(dev):
     from dream_gnn_amd import ops
 
     # full rectangle / triangular sweep (both directions overflow) / k > 16: the exact-row take-over kernel
-    # ... and the 256 x 256 LDS-DMA kernel (N >= 49152, k <= 16, D > 64): its wave lists fill (the groups of a cluster in one
+    # ... and the 256 x 256 LDS-DMA kernel (N >= 49152, D > 64): its wave lists fill (the groups of a cluster in one
     # quadrant), the regions of the clustered queries overflow in both directions, everything else goes through the pool
     for N, D, k in ((10000, 128, 4), (30000, 64, 4), (9000, 64, 40), (50000, 96, 4), (51000, 200, 12)):
         gen = torch.Generator().manual_seed(5)

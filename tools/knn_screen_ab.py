@@ -48,7 +48,7 @@ def timeit(fn, reps=3, warm=1):
 ok = True
 if "--check" in sys.argv:
     for N, D, k, cl in ((50001, 72, 6, False), (50000, 40, 3, False), (52000, 136, 5, True), (60000, 72, 40, False),
-                        (49152, 64, 4, True), (65000, 768, 4, False), (51000, 200, 20, True)):
+                        (49152, 64, 4, True), (65000, 768, 4, False), (51000, 200, 20, True), (50500, 96, 64, True), (70000, 768, 64, False)):
         ok &= check(N, D, k, cl)
 if "--time" in sys.argv:
     for N, D, k in ((100_000, 768, 4), (50_000, 768, 4), (100_000, 768, 64), (50_000, 768, 64)):

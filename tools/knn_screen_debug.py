@@ -33,7 +33,7 @@ thr = at; at += al(Np * 4)
 cnt = at; at += al(N * 9 * 4)
 buf = at; at += al(N * (8 * cap_r + cap_c) * 8)
 flags = at; at += al(N * 4)
-chunks = (N * (32 * k + 96) + 255) // 256 + 2048 if big and k <= 16 else 0
+chunks = (N * (16 * k + 48) + 255) // 256 + 2048 if big else 0
 pool = at; at += al(chunks * 256 * 16)
 ctl = at; at += al((chunks + 1) * 4 if chunks else 0)
 print("layout total", at, "==", need)

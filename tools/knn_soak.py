@@ -37,7 +37,7 @@ cases = 0
 # --big: only the sizes of the 256 x 256 screen tiles (N >= 49152: the phase-interleaved LDS-DMA kernel up to k = 16 and 2+ K
 # chunks, the register-staged one beyond)
 grid = ((55555, 80000, 131072), (96, 384, 768, 1024), (1, 2, 8, 16)) if "--big2" in sys.argv else \
-    ((49152, 50007, 66000), (40, 72, 200, 768), (1, 4, 16, 33)) if "--big" in sys.argv else \
+    ((49152, 50007, 66000), (40, 72, 200, 768), (1, 4, 16, 33, 64)) if "--big" in sys.argv else \
     ((1536, 2500, 4097, 9000, 20011, 26000, 45000), (8, 64, 200, 768), (1, 4, 16, 33, 64))
 for N in grid[0]:
     for D in grid[1]:
