@@ -44,7 +44,11 @@ def knn_sim_graph(n: int, k: int, seed: int, device):
     v = torch.ones(r.numel(), dtype=torch.float64, device=device)
     adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n)).coalesce()  # A + A^T + I
     idx, val = adj.indices(), adj.values()
-    rowsum = torch.zeros(n, dtype=torch.float64, device=device).index_add_(0, idx[0], val)
+    # (row sums as differences of a running sum between the row boundaries: exact for these integer values and without the
+    # float64 atomics of index_add_ — graph._normalized_adjacency)
+    bounds = torch.searchsorted(idx[0].contiguous(), torch.arange(n + 1, device=device))
+    run = torch.cat([torch.zeros(1, dtype=torch.float64, device=device), val.cumsum(0)])
+    rowsum = run[bounds[1:]] - run[bounds[:-1]]
     val = (val / rowsum[idx[0]]).to(torch.float32)
     return idx[0].to(torch.int32), idx[1].to(torch.int32), val
 
