@@ -757,6 +757,23 @@ def random_edge_dropout_sparse_views(adjs, dropout_rate: float = 0.1, generator:
 # ---------------------------------------------------------------------------------------------
 # (f4) similarity / feature kNN graph construction on the device
 # ---------------------------------------------------------------------------------------------
+def _coalesce_unit_entries(r: torch.Tensor, c: torch.Tensor, n: int):
+    """``sparse_coo_tensor(stack([r, c]), ones).coalesce()`` on the device without the library sort: the entries sorted by
+    (row, column) through two passes of the library's own stable record sort (by column, then by row: `dgmi_csr_from_coo_i32`),
+    equal neighbours merged, their multiplicity as the float64 value — the same indices and values, bit for bit (4.75 -> ~1.5 ms
+    on the 12.9 M entries of a kNN-64 graph of 100 000 nodes)."""
+    r32, c32 = r.to(torch.int32), c.to(torch.int32)
+    _, r_by_c, e1 = ops.csr_from_coo(c32, r32, n)            # entries in column order: their rows, and where they came from
+    c_by_c = c32[e1.long()]
+    _, c_sorted, e2 = ops.csr_from_coo(r_by_c, c_by_c, n)    # stable by row: columns ascending inside a row
+    r_sorted = r_by_c[e2.long()]
+    first = torch.ones(r_sorted.numel(), dtype=torch.bool, device=r.device)
+    first[1:] = (r_sorted[1:] != r_sorted[:-1]) | (c_sorted[1:] != c_sorted[:-1])
+    st = first.nonzero().squeeze(1)
+    counts = torch.diff(st, append=torch.tensor([r_sorted.numel()], device=r.device))
+    return torch.stack([r_sorted[st].long(), c_sorted[st].long()]), counts.to(torch.float64)
+
+
 def _normalized_adjacency(rows: torch.Tensor, cols: torch.Tensor, n: int, symm: bool) -> torch.Tensor:
     """data_loader.py:297-308 + utils.py:11-27 after the neighbour choice: ones COO ->
     (A + A^T if symm) -> + I -> D^-1 (.) -> sparse COO fp32, entries row-major sorted."""
@@ -767,9 +784,12 @@ def _normalized_adjacency(rows: torch.Tensor, cols: torch.Tensor, n: int, symm: 
     else:
         r = torch.cat([rows, eye])
         c = torch.cat([cols, eye])
-    v = torch.ones(r.numel(), dtype=torch.float64, device=rows.device)
-    adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n)).coalesce()
-    idx, val = adj.indices(), adj.values()
+    if r.is_cuda and n < 2 ** 31 and 2 ** 18 <= r.numel() < 2 ** 31:  # (below, the library's coalesce is as fast: 0.2-0.3 ms)
+        idx, val = _coalesce_unit_entries(r, c, n)
+    else:
+        v = torch.ones(r.numel(), dtype=torch.float64, device=rows.device)
+        adj = torch.sparse_coo_tensor(torch.stack([r, c]), v, (n, n)).coalesce()
+        idx, val = adj.indices(), adj.values()
     # row sums of the coalesced (row-major sorted) entries as differences of a running sum between the row boundaries: the
     # values are small integers (1 per edge, summed by the coalesce), so every partial sum is exact in float64 and the result
     # is bit for bit that of `index_add_` — whose float64 atomics took 39 ms on the 12.9 M entries of a kNN-64 graph of

@@ -803,6 +803,30 @@ def test_screened_knn_recomputes_overflowing_rows_exactly(dev):
         assert all(len(set(r.tolist())) == k for r in nbr[2990:3410].cpu())
 
 
+def test_adjacency_assembly_without_library_sort_or_atomics_is_bit_identical(dev):
+    """(r4, D2) `graph._normalized_adjacency` at scale: entries coalesced through the library's own record sort and row sums as
+    differences of a running sum — against the literal torch pipeline (`coalesce()` + float64 `index_add_`, data_loader.py:297-308,
+    utils.py:11-27): the same indices and the same values, bit for bit (duplicates, self loops, an isolated node)."""
+    from dream_gnn_amd import graph as G
+
+    gen = torch.Generator().manual_seed(11)
+    for n, k in ((40000, 9), (3000, 100)):
+        nbr = torch.randint(0, n - 1, (n, k), generator=gen)  # (node n - 1 is nobody's neighbour)
+        nbr[:, 1] = nbr[:, 0]                                  # duplicates inside a row
+        nbr[5] = 5                                             # self loops
+        rows = torch.arange(n).repeat_interleave(k).to(dev)
+        cols = nbr.reshape(-1).to(dev)
+        assert 2 * rows.numel() + n >= 2 ** 18
+        got = G._normalized_adjacency(rows, cols, n, True)
+        eye = torch.arange(n, device=dev)
+        r, c = torch.cat([rows, cols, eye]), torch.cat([cols, rows, eye])
+        adj = torch.sparse_coo_tensor(torch.stack([r, c]), torch.ones(r.numel(), dtype=torch.float64, device=dev), (n, n)).coalesce()
+        idx, val = adj.indices(), adj.values()
+        rowsum = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, idx[0], val)
+        want = (val * (1.0 / rowsum)[idx[0]]).to(torch.float32)
+        assert torch.equal(got._indices(), idx) and torch.equal(got._values(), want)
+
+
 def test_screened_knn_pool_that_runs_out_and_first_kernel_agree(dev):
     """(r4, f4) The 256 x 256 LDS-DMA screen kernel files what it keeps into a pool of record chunks; with the pool cut to a
     sliver (tuning knob) almost every record takes the direct-append fallback instead — the answer is the same exact top-k,
