@@ -932,22 +932,6 @@ __device__ __forceinline__ float wave_kth_largest(float (&v)[J], int k, int lane
   return m;
 }
 
-// tau0[q] = k-th largest of the sample scores (top four of each subset: 128 or 256 values) of query q, one wave per query
-template <int J>
-__global__ __launch_bounds__(256) void knn_tau_kernel(const float* __restrict__ part_val, int N, int Np, int k, float* __restrict__ tau0,
-                                                      float* __restrict__ thr) {
-  const int lane = threadIdx.x & 63, q = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= N) {
-    if (q < Np && lane == 0) thr[q] = 4.0f;  // a padding row offers and is offered nothing
-    return;
-  }
-  float v[J];
-#pragma unroll
-  for (int i = 0; i < J; ++i) v[i] = part_val[(int64_t)q * (64 * J) + lane + 64 * i];
-  const float t = wave_kth_largest<J>(v, k, lane);
-  if (lane == 0) tau0[q] = t, thr[q] = t - 2.f * kScreenEps;
-}
-
 // k-th largest of the values v[0..J) held per lane across the wave, by bisection on the order-preserving integer
 // image of the floats (32 counting rounds whatever k is; the extraction above costs k rounds).  Needs >= k values.
 template <int J>
@@ -970,6 +954,23 @@ __device__ __forceinline__ float wave_kth_largest_bisect(const float (&v)[J], in
   }
   const uint32_t u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
   return __uint_as_float(u);
+}
+
+// tau0[q] = k-th largest of the sample scores (top four of each subset: 128 or 256 values) of query q, one wave per query
+template <int J>
+__global__ __launch_bounds__(256) void knn_tau_kernel(const float* __restrict__ part_val, int N, int Np, int k, float* __restrict__ tau0,
+                                                      float* __restrict__ thr) {
+  const int lane = threadIdx.x & 63, q = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= N) {
+    if (q < Np && lane == 0) thr[q] = 4.0f;  // a padding row offers and is offered nothing
+    return;
+  }
+  float v[J];
+#pragma unroll
+  for (int i = 0; i < J; ++i) v[i] = part_val[(int64_t)q * (64 * J) + lane + 64 * i];
+  // (k rounds of extraction for small k; from k = 24 the 32 counting rounds of the bisection are fewer)
+  const float t = k >= 24 ? wave_kth_largest_bisect<J>(v, k) : wave_kth_largest<J>(v, k, lane);
+  if (lane == 0) tau0[q] = t, thr[q] = t - 2.f * kScreenEps;
 }
 
 // A wave's running top-k: lane i < k holds the i-th best (score desc, id asc).  Every lane passes the same (s, cid).
